@@ -1,0 +1,278 @@
+"""Seeded synthetic assets for the Multi-HMR inference path.
+
+There is no network in the build/bench environment, so neither the released
+checkpoints (``models/multiHMR/*.pt``), nor ``SMPLX_NEUTRAL.npz``, nor
+``smpl_mean_params.npz`` exist.  This module fabricates arrays of exactly the
+shapes / dtypes / key names the reference loads, so that the real files are a
+drop-in replacement when they are available:
+
+* ``make_smplx_data``   -> the keys of ``SMPLX_NEUTRAL.npz`` consumed through
+  ``smplx.create(SMPLX_DIR, 'smplx', ...)`` (reference blocks/smpl_layer.py:38).
+* ``make_mean_params``  -> ``models/smpl_mean_params.npz`` (reference model.py:442-462).
+* ``make_state_dict``   -> ``ckpt['model_state_dict']`` (reference demo.py:103), key names of
+  SURVEY.md Appendix A.1 / C.
+
+Nothing here is on the compute path; it only produces inputs.
+"""
+from __future__ import annotations
+
+import math
+import numpy as np
+import torch
+
+# ----------------------------------------------------------------------------------------------
+# SMPL-X topology constants (smplx package)
+# ----------------------------------------------------------------------------------------------
+SMPLX_NUM_VERTS = 10475
+SMPLX_NUM_FACES = 20908
+SMPLX_NUM_JOINTS = 55
+
+SMPLX_PARENTS = [
+    -1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 15, 15, 15,
+    20, 25, 26, 20, 28, 29, 20, 31, 32, 20, 34, 35, 20, 37, 38,
+    21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50, 21, 52, 53,
+]
+
+# vertex ids of the 21 "extra" joints appended by smplx's VertexJointSelector (smplx/vertex_ids.py)
+SMPLX_EXTRA_JOINT_VERTS = [
+    9120, 9929, 9448, 616, 6,            # nose, reye, leye, rear, lear
+    5770, 5780, 8846, 8463, 8474, 8635,  # LBigToe, LSmallToe, LHeel, RBigToe, RSmallToe, RHeel
+    5361, 4933, 5058, 5169, 5286,        # lthumb, lindex, lmiddle, lring, lpinky
+    8079, 7669, 7794, 7905, 8022,        # rthumb, rindex, rmiddle, rring, rpinky
+]
+
+_BODY = [
+    "pelvis", "left_hip", "right_hip", "spine1", "left_knee", "right_knee", "spine2", "left_ankle",
+    "right_ankle", "spine3", "left_foot", "right_foot", "neck", "left_collar", "right_collar", "head",
+    "left_shoulder", "right_shoulder", "left_elbow", "right_elbow", "left_wrist", "right_wrist",
+    "jaw", "left_eye_smplhf", "right_eye_smplhf",
+]
+_FINGERS = ["index", "middle", "pinky", "ring", "thumb"]
+_HANDS = [f"{s}_{f}{i}" for s in ("left", "right") for f in _FINGERS for i in (1, 2, 3)]
+_EXTRA = [
+    "nose", "right_eye", "left_eye", "right_ear", "left_ear", "left_big_toe", "left_small_toe", "left_heel",
+    "right_big_toe", "right_small_toe", "right_heel", "left_thumb", "left_index", "left_middle", "left_ring",
+    "left_pinky", "right_thumb", "right_index", "right_middle", "right_ring", "right_pinky",
+]
+_LMK = [f"face_landmark_{i}" for i in range(51)]
+#: first 127 entries of smplx.joint_names.JOINT_NAMES (reference utils/humans.py:25-26)
+SMPLX_JOINT_NAMES = _BODY + _HANDS + _EXTRA + _LMK
+assert len(SMPLX_JOINT_NAMES) == 127 and SMPLX_JOINT_NAMES[15] == "head" and SMPLX_JOINT_NAMES[55] == "nose"
+
+
+def make_smplx_data(seed: int = 0, num_verts: int = SMPLX_NUM_VERTS, num_faces: int = SMPLX_NUM_FACES,
+                    max_influences: int = 4) -> dict:
+    """A synthetic stand-in for ``SMPLX_NEUTRAL.npz`` with the real topology sizes.
+
+    Geometry is a crude 'blob per bone' body so that magnitudes (metres) are realistic: joints
+    form a chain with 5-25 cm bones, vertices sit within a few cm of their primary bone, skinning
+    weights have ``max_influences`` non-zeros per vertex and sum to one, the joint regressor rows
+    are convex combinations, pose correctives are mm-scale, shape directions cm-scale.
+    """
+    rng = np.random.RandomState(seed)
+    V, J = num_verts, SMPLX_NUM_JOINTS
+    parents = np.asarray(SMPLX_PARENTS, dtype=np.int64)
+
+    # template skeleton
+    jt = np.zeros((J, 3), dtype=np.float64)
+    for j in range(1, J):
+        bone = 0.04 if j >= 25 else 0.18  # fingers are short
+        d = rng.randn(3)
+        d /= np.linalg.norm(d)
+        jt[j] = jt[parents[j]] + bone * (0.6 + 0.4 * rng.rand()) * d
+
+    # vertices around a primary joint
+    primary = rng.randint(0, J, size=V)
+    primary[:J] = np.arange(J)  # every joint owns at least one vertex
+    v_template = jt[primary] + 0.035 * rng.randn(V, 3)
+
+    # skinning weights: primary, its parent, + random others
+    weights = np.zeros((V, J), dtype=np.float64)
+    for v in range(V):
+        js = {int(primary[v])}
+        p = int(parents[primary[v]])
+        if p >= 0:
+            js.add(p)
+        while len(js) < max_influences:
+            js.add(int(rng.randint(0, J)))
+        js = sorted(js)
+        w = rng.dirichlet(np.ones(len(js)) * 0.7)
+        weights[v, js] = w
+
+    # joint regressor: convex combination of 24 vertices owned by (or near) the joint
+    J_regressor = np.zeros((J, V), dtype=np.float64)
+    for j in range(J):
+        owned = np.nonzero(primary == j)[0]
+        pick = owned[:24] if len(owned) >= 24 else np.concatenate([owned, rng.randint(0, V, 24 - len(owned))])
+        w = rng.dirichlet(np.ones(len(pick)))
+        np.add.at(J_regressor[j], pick, w)
+
+    shapedirs = np.zeros((V, 3, 400), dtype=np.float32)
+    shapedirs[:, :, :16] = (0.012 * rng.randn(V, 3, 16)).astype(np.float32)        # betas (first 10/11 used)
+    shapedirs[:, :, 300:310] = (0.004 * rng.randn(V, 3, 10)).astype(np.float32)    # expression
+    posedirs = (0.0025 * rng.randn(V, 3, 486)).astype(np.float32)
+
+    f = rng.randint(0, V, size=(num_faces, 3)).astype(np.int64)
+    lmk_faces_idx = rng.randint(0, num_faces, size=51).astype(np.int64)
+    lmk_bary = rng.dirichlet(np.ones(3), size=51)
+
+    kintree = np.stack([np.where(parents < 0, 2 ** 32 - 1, parents), np.arange(J)]).astype(np.int64)
+    return {
+        "v_template": v_template.astype(np.float32),
+        "f": f,
+        "shapedirs": shapedirs,
+        "posedirs": posedirs,
+        "J_regressor": J_regressor.astype(np.float32),
+        "weights": weights.astype(np.float32),
+        "kintree_table": kintree,
+        "lmk_faces_idx": lmk_faces_idx,
+        "lmk_bary_coords": lmk_bary.astype(np.float32),
+    }
+
+
+def make_mean_params(seed: int = 0) -> dict:
+    """Stand-in for ``smpl_mean_params.npz``: keys pose[144] (24 x 6D), shape[10], cam[3]."""
+    rng = np.random.RandomState(seed + 1000)
+    ident6 = np.array([1, 0, 0, 0, 1, 0], dtype=np.float32)
+    pose = np.tile(ident6, 24) + 0.08 * rng.randn(144).astype(np.float32)
+    shape = (0.3 * rng.randn(10)).astype(np.float32)
+    cam = np.array([0.9, 0.0, 0.0], dtype=np.float32)
+    return {"pose": pose.astype(np.float32), "shape": shape, "cam": cam}
+
+
+VIT_CFG = {
+    "dinov2_vits14": dict(embed_dim=384, depth=12, num_heads=6),
+    "dinov2_vitb14": dict(embed_dim=768, depth=12, num_heads=12),
+    "dinov2_vitl14": dict(embed_dim=1024, depth=24, num_heads=16),
+}
+
+
+def _trunc_normal(gen, shape, std=0.02):
+    t = torch.empty(shape, dtype=torch.float32)
+    t.normal_(0.0, std, generator=gen)
+    return t.clamp_(-2 * std, 2 * std)
+
+
+def make_state_dict(backbone: str = "dinov2_vitl14", img_size: int = 896, xat_depth: int = 2,
+                    xat_num_heads: int = 8, num_betas: int = 10, seed: int = 0,
+                    depth_override: int | None = None, mean_params: dict | None = None,
+                    layerscale: float = 1.0) -> dict:
+    """Seeded random ``model_state_dict`` with the reference's key names and shapes.
+
+    Initialisation follows the reference constructors (DINOv2: trunc-normal(0.02) linears, zero bias,
+    LN 1/0, LayerScale ``layerscale``; heads/HPH: small normal) with two deliberate conditionings that a
+    trained checkpoint would also satisfy:
+      * ``decpose.bias`` moves init_body_pose joints 24..52 from the degenerate ``[1,0,0,1,0,0]`` to
+        ``[1,0,0,0,1,0]`` so that 6D->rotmat is well conditioned (the reference NaNs otherwise);
+      * read-out weights are small, so predictions are 'mean + small delta'.
+    """
+    cfg = dict(VIT_CFG[backbone])
+    if depth_override is not None:
+        cfg["depth"] = depth_override
+    C, L = cfg["embed_dim"], cfg["depth"]
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    p = "backbone.encoder."
+    sd[p + "cls_token"] = torch.empty(1, 1, C).normal_(0, 0.02, generator=g)
+    sd[p + "pos_embed"] = _trunc_normal(g, (1, 1 + 37 * 37, C))
+    sd[p + "mask_token"] = torch.zeros(1, C)
+    sd[p + "patch_embed.proj.weight"] = _trunc_normal(g, (C, 3, 14, 14), std=0.04)
+    sd[p + "patch_embed.proj.bias"] = torch.empty(C).normal_(0, 0.02, generator=g)
+    for i in range(L):
+        b = f"{p}blocks.{i}."
+        for n in ("norm1", "norm2"):
+            sd[b + n + ".weight"] = 1.0 + 0.1 * torch.empty(C).normal_(0, 1, generator=g)
+            sd[b + n + ".bias"] = 0.05 * torch.empty(C).normal_(0, 1, generator=g)
+        sd[b + "attn.qkv.weight"] = _trunc_normal(g, (3 * C, C), std=0.04)
+        sd[b + "attn.qkv.bias"] = 0.02 * torch.empty(3 * C).normal_(0, 1, generator=g)
+        sd[b + "attn.proj.weight"] = _trunc_normal(g, (C, C))
+        sd[b + "attn.proj.bias"] = 0.02 * torch.empty(C).normal_(0, 1, generator=g)
+        sd[b + "ls1.gamma"] = layerscale * (1.0 + 0.1 * torch.empty(C).normal_(0, 1, generator=g))
+        sd[b + "ls2.gamma"] = layerscale * (1.0 + 0.1 * torch.empty(C).normal_(0, 1, generator=g))
+        sd[b + "mlp.fc1.weight"] = _trunc_normal(g, (4 * C, C))
+        sd[b + "mlp.fc1.bias"] = 0.02 * torch.empty(4 * C).normal_(0, 1, generator=g)
+        sd[b + "mlp.fc2.weight"] = _trunc_normal(g, (C, 4 * C))
+        sd[b + "mlp.fc2.bias"] = 0.02 * torch.empty(C).normal_(0, 1, generator=g)
+    sd[p + "norm.weight"] = 1.0 + 0.1 * torch.empty(C).normal_(0, 1, generator=g)
+    sd[p + "norm.bias"] = 0.05 * torch.empty(C).normal_(0, 1, generator=g)
+
+    def lin(name, out_f, in_f, std=None, bias=True):
+        s = std if std is not None else 1.0 / math.sqrt(in_f)
+        sd[name + ".weight"] = s * torch.empty(out_f, in_f).normal_(0, 1, generator=g)
+        if bias:
+            sd[name + ".bias"] = 0.02 * torch.empty(out_f).normal_(0, 1, generator=g)
+
+    lin("mlp_classif.0", C, C)
+    lin("mlp_classif.2", 1, C)
+    lin("mlp_offset.0", C, C)
+    lin("mlp_offset.2", 2, C, std=0.2 / math.sqrt(C))
+
+    G = img_size // 14
+    Cc = C + 99
+    h = "x_attention_head."
+    for n in ("cross_queries_x", "cross_queries_y", "cross_values_x", "cross_values_y"):
+        sd[h + n] = 0.2 * torch.empty(G, Cc).normal_(0, 1, generator=g)
+    mp = mean_params if mean_params is not None else make_mean_params(seed)
+    init_body_pose = torch.eye(3).reshape(1, 3, 3).repeat(53, 1, 1)[:, :, :2].flatten(1).reshape(1, -1)
+    init_body_pose[:, : 24 * 6] = torch.from_numpy(np.asarray(mp["pose"], dtype=np.float32))
+    sd[h + "init_body_pose"] = init_body_pose
+    init_betas = torch.from_numpy(np.asarray(mp["shape"], dtype=np.float32)).unsqueeze(0)
+    sd[h + "init_betas_kid"] = torch.cat([init_betas, torch.zeros_like(init_betas[:, :1])], 1)
+    if num_betas == 11:
+        init_betas = torch.cat([init_betas, torch.zeros_like(init_betas[:, :1])], 1)
+    sd[h + "init_betas"] = init_betas
+    sd[h + "init_cam"] = torch.from_numpy(np.asarray(mp["cam"], dtype=np.float32)).unsqueeze(0)
+    sd[h + "init_expression"] = torch.zeros(1, 10)
+
+    dim, inner, mlp_dim = 1024, 32 * xat_num_heads, 1024
+    token_dim = 318 + num_betas + 3 + Cc
+    t = h + "transformer."
+    sd[t + "pos_embedding"] = torch.empty(1, 1, dim).normal_(0, 1, generator=g)
+    lin(t + "to_token_embedding", dim, token_dim)
+    for l in range(xat_depth):
+        b = f"{t}transformer.layers.{l}."
+        for k in range(3):
+            sd[f"{b}{k}.norm.weight"] = 1.0 + 0.1 * torch.empty(dim).normal_(0, 1, generator=g)
+            sd[f"{b}{k}.norm.bias"] = 0.05 * torch.empty(dim).normal_(0, 1, generator=g)
+        lin(b + "0.fn.to_qkv", 3 * inner, dim, bias=False)
+        lin(b + "0.fn.to_out.0", dim, inner)
+        lin(b + "1.fn.to_kv", 2 * inner, Cc, bias=False)
+        lin(b + "1.fn.to_q", inner, dim, bias=False)
+        lin(b + "1.fn.to_out.0", dim, inner)
+        lin(b + "2.fn.net.0", mlp_dim, dim)
+        lin(b + "2.fn.net.3", dim, mlp_dim)
+    small = 0.15 / math.sqrt(dim)
+    lin(h + "decpose", 318, dim, std=small)
+    lin(h + "decshape", num_betas, dim, std=small)
+    lin(h + "deccam", 3, dim, std=small)
+    lin(h + "decexpression", 10, dim, std=small)
+    # Appendix B.6 conditioning: init+bias == [1,0,0,0,1,0] for joints 24..52
+    bias = sd[h + "decpose.bias"]
+    ident6 = torch.tensor([1.0, 0, 0, 0, 1, 0])
+    for j in range(24, 53):
+        bias[6 * j: 6 * j + 6] = ident6 - init_body_pose[0, 6 * j: 6 * j + 6] + 0.01 * torch.empty(6).normal_(0, 1, generator=g)
+    return sd
+
+
+def get_camera_K(img_size: int, batch: int = 1, fov: float = 60.0) -> torch.Tensor:
+    """K of reference demo.py:53-68 (fx=fy=S/(2 tan(fov/2)), principal point S//2), repeated."""
+    K = torch.eye(3)
+    focal = img_size / (2 * np.tan(np.radians(fov) / 2))
+    K[0, 0], K[1, 1] = focal, focal
+    K[0, -1], K[1, -1] = img_size // 2, img_size // 2
+    return K.unsqueeze(0).repeat(batch, 1, 1)
+
+
+def make_pinned_idx(batch: int, grid: int, per_image: int, seed: int = 0):
+    """Seeded distinct (y, x) cells per image, sorted like ``torch.where`` would return them
+    (ascending b, y, x; reference model.py:146-149).  Used through the reference's own
+    ``idx=...``/``is_training=True`` hook (model.py:141-151) to pin the number of persons."""
+    g = torch.Generator().manual_seed(seed + 77)
+    bs, ys, xs = [], [], []
+    for b in range(batch):
+        cells = torch.randperm(grid * grid, generator=g)[:per_image].sort().values
+        bs.append(torch.full((per_image,), b, dtype=torch.long))
+        ys.append(cells // grid)
+        xs.append(cells % grid)
+    b, y, x = torch.cat(bs), torch.cat(ys), torch.cat(xs)
+    return (b, y, x, torch.zeros_like(b))
