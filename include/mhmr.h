@@ -1,0 +1,218 @@
+/* libmhmr.so -- C ABI of the MI355X-native Multi-HMR batched-inference path.
+ *
+ * The reference (naver/multi-hmr) has no FFI / operator layer: its only seam is the Python class
+ * model.Model (reference model.py:30-349) whose forward dispatches PyTorch library kernels.  This header is
+ * the boundary a maintainer would bind instead; every entry point names the reference code it replaces.
+ *
+ * Conventions: extern "C"; raw DEVICE pointers (tensor.data_ptr()) and explicit int shapes; caller-allocated
+ * outputs and workspaces; `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ * no allocation, no hidden synchronisation, no exceptions: every call returns 0 on success, a negative
+ * MHMR_ERR_* for argument errors or a positive hipError_t.  All matrices are row-major.  "op16" means the 16-bit
+ * MFMA operand type selected by `dtype` (MHMR_DT_BF16 or MHMR_DT_F16; fp32 accumulation either way).
+ */
+#ifndef MHMR_H
+#define MHMR_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MHMR_VERSION 100
+
+#define MHMR_OK 0
+#define MHMR_ERR_BAD_ARG (-1)
+#define MHMR_ERR_BAD_SHAPE (-2)
+
+#define MHMR_DT_BF16 0
+#define MHMR_DT_F16 1
+
+#define MHMR_ACT_NONE 0
+#define MHMR_ACT_RELU 1
+#define MHMR_ACT_GELU 2
+
+/* GEMM epilogues of mhmr_gemm16 */
+#define MHMR_EPI_OP16 0      /* out16 = acc + bias                                           */
+#define MHMR_EPI_OP16_GELU 1 /* out16 = gelu_erf(acc + bias)            (DINOv2 Mlp fc1)     */
+#define MHMR_EPI_OP16_RELU 2 /* out16 = relu(acc + bias)                (regression_mlp, model.py:596-609) */
+#define MHMR_EPI_RESID 3     /* out32 += gamma * (acc + bias)           (LayerScale + residual) */
+#define MHMR_EPI_PATCH 4     /* patch-embed: + bias + pos-embed, scattered to token rows     */
+#define MHMR_EPI_F32 5       /* out32 = acc (+ bias)                    (HPH to_kv)          */
+#define MHMR_EPI_VT 6        /* V^T[b][h][d][swap23(t)] = acc + bias    (attention V operand) */
+
+int mhmr_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * ViT backbone.  Replaces blocks/dinov2.py:16-26 -> torch.hub DinoVisionTransformer.get_intermediate_layers
+ * (patch embed + cls + interpolated pos-embed, L pre-norm blocks with LayerScale, final LayerNorm, cls dropped).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float *ln1_w, *ln1_b;   /* [C]                                  blocks.i.norm1            */
+    const void* qkv_w;            /* op16 [3C, C]                         blocks.i.attn.qkv.weight  */
+    const float* qkv_b;           /* [3C]                                                            */
+    const void* proj_w;           /* op16 [C, C]                          blocks.i.attn.proj        */
+    const float *proj_b, *ls1;    /* [C], [C] (ls1.gamma)                                           */
+    const float *ln2_w, *ln2_b;   /* [C]                                  blocks.i.norm2            */
+    const void* fc1_w;            /* op16 [4C, C]                         blocks.i.mlp.fc1          */
+    const float* fc1_b;           /* [4C]                                                            */
+    const void* fc2_w;            /* op16 [C, 4C]                         blocks.i.mlp.fc2          */
+    const float *fc2_b, *ls2;     /* [C], [C] (ls2.gamma)                                           */
+} mhmr_vit_block;
+
+typedef struct {
+    int dtype;              /* MHMR_DT_*                                                                  */
+    int B, S, C, H, L;      /* images, image size (S % 14 == 0), embed dim (= 64 H), heads, depth         */
+    int G, N, T, Tp;        /* S/14, G*G, N+1, T rounded up to a multiple of 128                          */
+    int Kp;                 /* 588 rounded up to a multiple of 64 (= 640)                                 */
+    const void* patch_w;    /* op16 [C, Kp]      patch_embed.proj.weight flattened (c,py,px), zero padded */
+    const float* patch_b;   /* [C]                                                                        */
+    const float* cls_pos0;  /* [C]               cls_token + pos[0]                                       */
+    const float* pos;       /* [1+N, C]          pos_embed bicubically interpolated to G x G (host, once) */
+    const mhmr_vit_block* blocks; /* HOST array of L block descriptors                                    */
+    const float *norm_w, *norm_b; /* [C]          final norm                                              */
+    /* workspaces (device) */
+    void* a_patch;          /* op16 [roundup(B*N,128), Kp]   rows >= B*N must be zero                     */
+    float* resid;           /* [B*Tp, C]        fp32 residual stream                                      */
+    void* xn;               /* op16 [B*Tp, C]                                                             */
+    void* qk;               /* op16 [B*Tp, 2C]  (Q | K)                                                   */
+    void* vt;               /* op16 [B, H, 64, Tp]                                                        */
+    void* att;              /* op16 [B*Tp, C]                                                             */
+    void* hid;              /* op16 [B*Tp, 4C]                                                            */
+} mhmr_vit_desc;
+
+/* x: [B,3,S,S] fp32 (ImageNet-normalised).  feat32: [B*N, C] fp32 patch features (token n = y*G + x).
+ * ctx16: op16 [>= B*N rows, ldctx]; columns [0, C) receive the 16-bit copy of feat32.                       */
+int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void* ctx16, int ldctx, void* stream);
+
+/* Building blocks, exported for unit tests and bisecting. */
+int mhmr_gemm16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias,
+                const float* gamma, void* out, int ldo, const float* pos, int Np, int Tp, int H, int Mvalid, int epi,
+                int dtype, void* stream);
+int mhmr_attention16(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype,
+                     void* stream);
+int mhmr_layernorm16(const float* in, const float* w, const float* b, void* out16, int rows, int C, float eps,
+                     int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Detection head.  Replaces Model.detection (model.py:133-158): mlp_classif -> sigmoid clamp (641-643) ->
+ * max-pool NMS (620-638) -> threshold (612-617) -> (b, y, x) coordinates in torch.where order.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* scores[m] = clamp(sigmoid(hid16[m] . w2 + b2), 1e-4, 1 - 1e-4); hid16 = relu(mlp_classif.0(features)) from
+ * mhmr_gemm16(..., MHMR_EPI_OP16_RELU).                                                                      */
+int mhmr_detect_scores(const void* hid16, int ld, const float* w2, const float* b2, float* scores, int rows, int C,
+                       int dtype, void* stream);
+/* pass 1: counts[b] = number of cells with nms(score) >= thr.  pass 2 (after the host prefix sum `base`):
+ * ordered compaction into det_b/det_y/det_x/det_score.                                                       */
+int mhmr_detect_count(const float* scores, int B, int G, int nms_kernel, float thr, int* counts, void* stream);
+int mhmr_detect_write(const float* scores, int B, int G, int nms_kernel, float thr, const int* base, int* det_b,
+                      int* det_y, int* det_x, float* det_score, void* stream);
+
+/* Camera embedding.  Replaces Model.embedd_camera (model.py:160-187) + inverse_perspective_projection
+ * (utils/camera.py:30-48) + FourierPositionEncoding (blocks/camera_embed.py:9-58).  zK: [B*N, 99] fp32; also
+ * writes op16 copies to ctx16[:, C:C+99] and zeros ctx16[:, C+99:ldctx].  freq: [3*16] linspace(1, 32, 16) x3.   */
+int mhmr_camera_embed(const float* K, const float* freq, int B, int G, int patch, float* zK, void* ctx16, int ldctx,
+                      int C, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Human Perception Head.  Replaces HPH.cross_attn_inputs / HPH.forward (model.py:479-593), TransformerDecoder
+ * (blocks/cross_attn_transformer.py:302-359), rot6d_to_rotmat (utils/humans.py:12-22), roma.rotmat_to_rotvec
+ * (model.py:291), Model.to_euclidean_dist (model.py:189-203), mlp_offset + loc (model.py:258, 272-275).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float *ln_sa_w, *ln_sa_b;  /* layers.l.0.norm                                  */
+    const float* to_qkv;             /* [3*inner, dim]      layers.l.0.fn.to_qkv.weight  */
+    const float *sa_out_w, *sa_out_b;/* [dim, inner],[dim]  layers.l.0.fn.to_out.0       */
+    const float *ln_ca_w, *ln_ca_b;  /* layers.l.1.norm                                  */
+    const void* to_kv16;             /* op16 [2*inner, Kc]  layers.l.1.fn.to_kv.weight, zero-padded columns */
+    const float* to_q;               /* [inner, dim]        layers.l.1.fn.to_q.weight    */
+    const float *ca_out_w, *ca_out_b;/* [dim, inner],[dim]  layers.l.1.fn.to_out.0       */
+    const float *ln_ff_w, *ln_ff_b;  /* layers.l.2.norm                                  */
+    const float *ff1_w, *ff1_b;      /* [mlp, dim],[mlp]    layers.l.2.fn.net.0          */
+    const float *ff2_w, *ff2_b;      /* [dim, mlp],[dim]    layers.l.2.fn.net.3          */
+} mhmr_hph_layer;
+
+typedef struct {
+    int dtype;
+    int C, G, N;                 /* backbone dim, grid, tokens per image                                      */
+    int Kc;                      /* context operand width: C + 99 rounded up to a multiple of 64             */
+    int dim, heads, mlp, depth;  /* 1024, xat_num_heads, 1024, xat_depth (model.py:122-126)                   */
+    int nb;                      /* num_betas                                                                */
+    int Ktok;                    /* token width C + 99 + 318 + nb + 3 rounded up to a multiple of 16         */
+    int Ndec;                    /* 318 + nb + 3 + 10                                                        */
+    int patch;                   /* 14                                                                       */
+    int nearness;                /* model.py:196                                                             */
+    float fn;                    /* S / (2 tan(30 deg)): focal length of the normalising 60-degree camera (utils/camera.py:71-77) */
+    const float *off1_w, *off1_b, *off2_w, *off2_b; /* mlp_offset.{0,2}: [C,C],[C],[2,C],[2]                  */
+    const float *cq_x, *cq_y, *cv_x, *cv_y;         /* cross_{queries,values}_{x,y}: [G, C+99]                */
+    const float* init_tail;      /* [318 + nb + 3] = init_body_pose | init_betas | init_cam                   */
+    const float *tok_w, *tok_b;  /* to_token_embedding: [dim, Ktok] (zero padded), [dim] (+ pos_embedding[:,0]) */
+    const mhmr_hph_layer* layers;/* HOST array of `depth`                                                    */
+    const float *dec_w, *dec_b;  /* [Ndec, dim], [Ndec]: decpose|decshape|deccam|decexpression stacked, bias has the init_* added */
+    /* workspaces for P persons (device, fp32 unless noted) */
+    float* zc;      /* [P, C]        */
+    float* token;   /* [P, Ktok]     */
+    float* x;       /* [P, dim]      */
+    float* xn;      /* [P, dim]      */
+    float* t1;      /* [P, max(3*inner, mlp, C)] */
+    float* t2;      /* [P, inner]    */
+    float* kv;      /* [Mctx, 2*inner], Mctx = roundup(B*N, 128) */
+    float* dec;     /* [P, Ndec]     */
+    int* det_row;   /* [P]           */
+} mhmr_hph_desc;
+
+/* Inputs: feat32 [B*N, C], zK [B*N, 99], ctx16 op16 [Mctx, Kc] (features | camera | 0), detections det_{b,y,x}
+ * [P] (sorted by (b, y, x)), gstart [ngroups+1] = person offsets of the non-empty images, chunks [nchunks*3] =
+ * (image b, first person, count <= 8) cross-attention work items, K [B,3,3].
+ * Outputs: offset [P,2], loc [P,2], rotmat [P,53,3,3], rotvec [P,53,3], betas [P,nb], expr [P,10],
+ * dist_pp [P] (raw), dist [P] (post-processed).                                                              */
+int mhmr_hph_forward(const mhmr_hph_desc* d, const float* feat32, const float* zK, void* ctx16, const int* det_b,
+                     const int* det_y, const int* det_x, int P, const int* gstart, int ngroups, int nmax,
+                     const int* chunks, int nchunks, const float* K, int B, float* offset, float* loc, float* rotmat,
+                     float* rotvec, float* betas, float* expr, float* dist_pp, float* dist, void* stream);
+
+/* Building blocks (unit tests). */
+int mhmr_linear_f32(const float* X, int ldx, const int* row_idx, const float* W, int ldw, const float* bias,
+                    const float* R, int ldr, float* Y, int ldy, int M, int N, int K, int act, void* stream);
+int mhmr_layernorm_f32(const float* in, const float* w, const float* b, float* out, int rows, int C, float eps,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * SMPL-X layer.  Replaces SMPL_Layer.forward (blocks/smpl_layer.py:47-155) -> smplx.SMPLX.forward / lbs,
+ * roma.rotvec_to_rotmat (:107), inverse_perspective_projection (:117-123), perspective_projection (:143-144).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int V, Vp;            /* 10475, V rounded up to a multiple of 64                                         */
+    int Kb;               /* 486 + nb + 10 + 1 rounded up to a multiple of 16                                */
+    int nb, Kinf;         /* num_betas, max skinning influences per vertex                                   */
+    int center_joint;     /* JOINT_NAMES.index(person_center) = 15 ('head')                                  */
+    const float* basis4;  /* [Kb/4][3][Vp][4]: rows = posedirs(486) | shapedirs(nb) | exprdirs(10) | v_template */
+    const float* J0;      /* [55*3]            J_regressor . v_template                                      */
+    const float* JS;      /* [55*3][nb+10]     J_regressor . [shapedirs | exprdirs]                          */
+    const int* parents;   /* [55]                                                                            */
+    const int* skin_idx;  /* [V][Kinf]                                                                       */
+    const float* skin_w;  /* [V][Kinf]                                                                       */
+    const int* extra_vid; /* [21]              vertex ids of joints 55..75                                   */
+    const int* lmk_vidx;  /* [51*3]            faces[lmk_faces_idx]                                          */
+    const float* lmk_bary;/* [51*3]                                                                          */
+} mhmr_lbs_consts;
+
+/* rotvec [P,53,3], betas [P,nb], expr [P,10], loc [P,2], dist [P], K [B,3,3], det_b [P] (image of each person).
+ * Workspaces: ws_F [roundup(P,16), Kb], ws_A [P,55,12], ws_xf [P,24].
+ * Outputs: v3d [P,V,3], v2d [P,V,2], j3d [P,127,3], j2d [P,127,2], transl [P,3]  (transl_pelvis = j3d[:,0]). */
+int mhmr_lbs_forward(const mhmr_lbs_consts* c, const float* rotvec, const float* betas, const float* expr,
+                     const float* loc, const float* dist, const float* K, const int* det_b, int P, float* ws_F,
+                     float* ws_A, float* ws_xf, float* v3d, float* v2d, float* j3d, float* j2d, float* transl,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Measurement: hipEvent brackets around every launch of one kernel family (0 = GEMM, 1 = attention, 2 = LBS
+ * vertex kernel), recorded on the launch stream.  enable(kind >= 0) starts a fresh window, enable(-1) stops;
+ * collect() synchronises the recorded events and returns launches, summed milliseconds and summed work
+ * (FLOPs for 0/1, persons for 2).
+ * ---------------------------------------------------------------------------------------------------------- */
+int mhmr_prof_enable(int kind);
+int mhmr_prof_collect(int* launches, double* total_ms, double* total_work);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MHMR_H */

@@ -1,0 +1,123 @@
+"""ctypes binding of ``libmhmr.so`` (C ABI declared in include/mhmr.h).
+
+The HIP library is the product: there is NO CPU / PyTorch fallback.  If the shared object is missing or an
+entry point fails, loading raises and every op raises -- loudly, by design.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libmhmr.so")
+SOURCES = ["gemm.hip", "attention.hip", "vit_misc.hip", "hph.hip", "lbs.hip", "capi.hip"]
+HEADERS = ["mhmr_common.h", "mhmr_internal.h", os.path.join("..", "..", "include", "mhmr.h")]
+
+DT_BF16, DT_F16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+EPI_OP16, EPI_OP16_GELU, EPI_OP16_RELU, EPI_RESID, EPI_PATCH, EPI_F32, EPI_VT = range(7)
+
+_vp, _fp, _ip, _i, _f = C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float  # all device pointers are void*
+
+
+class MhmrError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP translation unit for gfx950 into csrc/libmhmr.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    if not force and os.path.isfile(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise MhmrError("hipcc failed:\n" + res.stdout + res.stderr)
+    return LIB_PATH
+
+
+class VitBlock(C.Structure):
+    _fields_ = [(n, _vp) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1", "ln2_w", "ln2_b",
+                                   "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+
+
+class VitDesc(C.Structure):
+    _fields_ = ([(n, _i) for n in ("dtype", "B", "S", "C", "H", "L", "G", "N", "T", "Tp", "Kp")] +
+                [("patch_w", _vp), ("patch_b", _vp), ("cls_pos0", _vp), ("pos", _vp), ("blocks", C.POINTER(VitBlock)),
+                 ("norm_w", _vp), ("norm_b", _vp)] +
+                [(n, _vp) for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid")])
+
+
+class HphLayer(C.Structure):
+    _fields_ = [(n, _vp) for n in ("ln_sa_w", "ln_sa_b", "to_qkv", "sa_out_w", "sa_out_b", "ln_ca_w", "ln_ca_b", "to_kv16",
+                                   "to_q", "ca_out_w", "ca_out_b", "ln_ff_w", "ln_ff_b", "ff1_w", "ff1_b", "ff2_w", "ff2_b")]
+
+
+class HphDesc(C.Structure):
+    _fields_ = ([(n, _i) for n in ("dtype", "C", "G", "N", "Kc", "dim", "heads", "mlp", "depth", "nb", "Ktok", "Ndec", "patch",
+                                   "nearness")] + [("fn", _f)] +
+                [(n, _vp) for n in ("off1_w", "off1_b", "off2_w", "off2_b", "cq_x", "cq_y", "cv_x", "cv_y", "init_tail",
+                                    "tok_w", "tok_b")] + [("layers", C.POINTER(HphLayer))] +
+                [(n, _vp) for n in ("dec_w", "dec_b", "zc", "token", "x", "xn", "t1", "t2", "kv", "dec", "det_row")])
+
+
+class LbsConsts(C.Structure):
+    _fields_ = ([(n, _i) for n in ("V", "Vp", "Kb", "nb", "Kinf", "center_joint")] +
+                [(n, _vp) for n in ("basis4", "J0", "JS", "parents", "skin_idx", "skin_w", "extra_vid", "lmk_vidx", "lmk_bary")])
+
+
+_SIGS = {
+    "mhmr_version": ([], _i),
+    "mhmr_vit_forward": ([C.POINTER(VitDesc), _vp, _vp, _vp, _i, _vp], _i),
+    "mhmr_gemm16": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "mhmr_attention16": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "mhmr_layernorm16": ([_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp], _i),
+    "mhmr_detect_scores": ([_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
+    "mhmr_detect_count": ([_vp, _i, _i, _i, _f, _vp, _vp], _i),
+    "mhmr_detect_write": ([_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "mhmr_camera_embed": ([_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp], _i),
+    "mhmr_hph_forward": ([C.POINTER(HphDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i,
+                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "mhmr_linear_f32": ([_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp], _i),
+    "mhmr_layernorm_f32": ([_vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
+    "mhmr_lbs_forward": ([C.POINTER(LbsConsts)] + [_vp] * 7 + [_i] + [_vp] * 8 + [_vp], _i),
+    "mhmr_prof_enable": ([_i], _i),
+    "mhmr_prof_collect": ([C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)], _i),
+}
+
+#: every symbol include/mhmr.h declares
+EXPORTS = tuple(_SIGS.keys())
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) the in-tree libmhmr.so; raise if it is absent -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise MhmrError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950). The Multi-HMR path has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(l, name)          # AttributeError if the symbol is not exported
+            fn.argtypes, fn.restype = args, res
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = {-1: "bad argument", -2: "bad shape"}.get(rc, f"hipError_t {rc}")
+        raise MhmrError(f"{what} failed: {kind}")
+
+
+def ptr(t) -> int | None:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,179 @@
+// Flash-style multi-head self-attention forward for the DINOv2 blocks, head_dim = 64, non-causal,
+// T = N + 1 tokens padded to Tp (multiple of 128); keys >= T are masked.
+//
+// gfx950 structure: one workgroup = 4 waves = 128 query rows of one (image, head); each wave owns 32 query
+// rows.  Per 64-key tile:  S^T = K . Q^T  (8 x v_mfma_f32_32x32x16, "swapped" so a lane owns ONE query column
+// and 32 of the 64 keys -> row max / row sum are lane-local plus one lane^32 exchange), online softmax in
+// fp32 registers, P packed to 16-bit in place as the B operand of  O^T += V^T . P^T  (8 MFMAs).  V arrives
+// already transposed and key-permuted (bits 2<->3 of the key index swapped inside every 16-key group, written
+// that way by the V GEMM epilogue), so the lane that holds P for keys {16s+4hi+0..3, 16s+8+4hi+0..3} reads the
+// matching V^T operand as ONE ds_read_b128 -- no cross-lane shuffle and no LDS transpose.
+// K and V^T tiles ([64][64] 16-bit = 128-byte rows) are DMA'd by global_load_lds_dwordx4 into double-buffered
+// LDS with the chunk XOR swizzle on the source address; one barrier per KV tile.
+#include "mhmr_common.h"
+#include "mhmr_internal.h"
+
+namespace {
+
+constexpr int QB = 128, KB = 64;
+constexpr int KV_TILE_BYTES = KB * 64 * 2;  // 8 KiB
+
+template <int DT>
+__global__ __launch_bounds__(256, 2) void attn_kernel(const void* __restrict__ qk_, const void* __restrict__ vt_,
+                                                      void* __restrict__ out_, int T, int Tp, int C, int H,
+                                                      int nqt, float scale_log2e) {
+    typedef typename Op<DT>::T Tt;
+    typedef typename Op<DT>::V8 V8;
+    typedef typename Op<DT>::V4 V4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | Vt tile]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = bid % nqt, bh = bid / nqt;
+    const int b = bh / H, h = bh - b * H;
+
+    const Tt* qk = (const Tt*)qk_;
+    const Tt* vt = (const Tt*)vt_;
+    const int ldq = 2 * C;
+    const size_t row0 = (size_t)b * Tp;
+
+    // ---- Q fragments (B operand: lane (q = l31, hi) holds Q[q][16 ks + 8 hi + 0..7]) ----
+    const int q_row = qt * QB + 32 * w + l31;
+    V8 qf[4];
+    {
+        const Tt* qp = qk + (row0 + q_row) * ldq + h * 64 + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const V8*)(qp + 16 * ks);
+    }
+
+    // ---- staging addresses ----
+    const int srow = tid >> 3;                                 // 0..31 (+32 on the second pass)
+    const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
+    const Tt* k_src = qk + (row0 + srow) * ldq + C + h * 64 + schunk * 8;                 // + key0 * ldq
+    const Tt* v_src = vt + ((size_t)(b * H + h) * 64 + srow) * Tp + schunk * 8;           // + key0
+    auto stage = [&](int j, int buf) {
+        char* sk = smem + buf * (2 * KV_TILE_BYTES) + w * 1024;
+        char* sv = sk + KV_TILE_BYTES;
+        const Tt* kp = k_src + (size_t)j * KB * ldq;
+        const Tt* vp = v_src + j * KB;
+        glds16(kp, sk);
+        glds16(kp + (size_t)32 * ldq, sk + 4096);
+        glds16(vp, sv);
+        glds16(vp + (size_t)32 * Tp, sv + 4096);
+    };
+
+    const int fsw = (lane >> 1) & 7;
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;  // running max (scaled, log2 domain) and this lane's partial row sum
+
+    const int ntile = (T + KB - 1) / KB;
+    stage(0, 0);
+    for (int j = 0; j < ntile; ++j) {
+        __syncthreads();
+        if (j + 1 < ntile) stage(j + 1, (j + 1) & 1);
+        const char* sk = smem + (j & 1) * (2 * KV_TILE_BYTES);
+        const char* sv = sk + KV_TILE_BYTES;
+
+        // ---- S^T = K . Q^T ----
+        f32x16 s[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const V8 kf = *(const V8*)(sk + (32 * sub + l31) * 128 + (((2 * ks + hi) ^ fsw) * 16));
+                s[sub] = Op<DT>::mfma32(kf, qf[ks], s[sub]);
+            }
+        }
+        // ---- mask keys >= T (only the last tile can contain them) ----
+        if (j * KB + KB > T) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (j * KB + 32 * sub + crow(r, hi) >= T) s[sub][r] = -INFINITY;
+        }
+        // ---- online softmax (one query row per lane pair {l, l^32}) ----
+        float mt = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[1][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt * scale_log2e);
+        if (!__all(m_new == m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            m_run = m_new;
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[sub][r] * scale_log2e - m_run);
+                s[sub][r] = p;
+                psum += p;
+            }
+        l_run += psum;
+
+        // ---- O^T += V^T . P^T ----
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            V8 pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = (Tt)s[st >> 1][8 * (st & 1) + e];
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) {
+                const V8 vf = *(const V8*)(sv + (32 * ds + l31) * 128 + (((2 * st + hi) ^ fsw) * 16));
+                o[ds] = Op<DT>::mfma32(vf, pf, o[ds]);
+            }
+        }
+    }
+
+    // ---- normalise and store: lane (q, hi) holds O[q][32 ds + 8 rg + 4 hi + 0..3] ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    Tt* op = (Tt*)out_ + (row0 + q_row) * C + h * 64 + 4 * hi;
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            V4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (Tt)(o[ds][4 * rg + e] * inv);
+            *(V4*)(op + 32 * ds + 8 * rg) = v;
+        }
+}
+
+}  // namespace
+
+int mhmr_launch_attention(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype,
+                          hipStream_t s) {
+    if (C != H * 64 || Tp % QB || T > Tp || T <= 0) return MHMR_ERR_BAD_SHAPE;
+    const int nqt = Tp / QB;
+    const int grid = nqt * H * B;
+    const size_t lds = 4 * KV_TILE_BYTES;
+    const float scale_log2e = 0.125f * 1.44269504088896340736f;
+    prof_begin(PROF_ATTN, s);
+    if (dtype == MHMR_DT_F16)
+        hipLaunchKernelGGL((attn_kernel<MHMR_DT_F16>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, scale_log2e);
+    else
+        hipLaunchKernelGGL((attn_kernel<MHMR_DT_BF16>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, scale_log2e);
+    prof_end(PROF_ATTN, s, 4.0 * B * H * (double)T * T * 64);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}

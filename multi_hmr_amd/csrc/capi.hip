@@ -1,0 +1,233 @@
+// extern "C" entry points of libmhmr.so (declared in include/mhmr.h): the ViT and HPH forward orchestration
+// (pure launch sequences on the caller's stream, no allocation, no synchronisation) and the hipEvent profiler.
+#include <vector>
+#include <mutex>
+#include "mhmr_common.h"
+#include "mhmr_internal.h"
+
+// launchers defined in the other translation units
+int mhmr_launch_attention(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, hipStream_t s);
+int mhmr_launch_im2col(const float* x, void* a, int B, int S, int G, int Kp, int dtype, hipStream_t s);
+int mhmr_launch_init_rows(float* resid, const float* cls_pos0, int B, int T, int Tp, int C, hipStream_t s);
+int mhmr_launch_layernorm(const float* in, const float* w, const float* b, void* out16, int rows, int C, float eps, int dtype, hipStream_t s);
+int mhmr_launch_final_norm(const float* resid, const float* w, const float* b, void* ctx16, int ldctx, float* feat32, int B, int Np, int Tp, int C, float eps, int dtype, hipStream_t s);
+int mhmr_launch_linear_f32(const float* X, int ldx, const int* row_idx, const float* W, int ldw, const float* bias, const float* R, int ldr, float* Y, int ldy, int M, int N, int K, int act, hipStream_t s);
+int mhmr_launch_layernorm_f32(const float* in, const float* w, const float* b, float* out, int rows, int C, float eps, hipStream_t s);
+int mhmr_launch_scores(const void* hid, int ld, const float* w2, const float* b2, float* scores, int rows, int C, int dtype, hipStream_t s);
+int mhmr_launch_detect_count(const float* scores, int B, int G, int nms_kernel, float thr, int* counts, hipStream_t s);
+int mhmr_launch_detect_write(const float* scores, int B, int G, int nms_kernel, float thr, const int* base, int* det_b, int* det_y, int* det_x, float* det_score, hipStream_t s);
+int mhmr_launch_camera_embed(const float* Kmat, const float* freq, int B, int G, int patch, float* zK, void* ctx16, int Kc, int C, int dtype, hipStream_t s);
+int mhmr_launch_hph_inputs(const float* feat32, const float* zK, const int* det_b, const int* det_y, const int* det_x, const float* cq_x, const float* cq_y, const float* cv_x, const float* cv_y, const float* init_tail, int ntail, float* zc, float* token, int Ktok, void* ctx16, int Kc, int* det_row, int P, int G, int C, int dtype, hipStream_t s);
+int mhmr_launch_hph_self_attn(const float* qkv, const int* gstart, float* out, int ngroups, int nmax, int heads, hipStream_t s);
+int mhmr_launch_hph_cross_attn(const float* q, const float* kv, const int* chunks, int nchunks, float* out, int heads, int N, hipStream_t s);
+int mhmr_launch_hph_decode(const float* dec, int ldd, int nb, const float* Kmat, const int* det_b, float fn, int nearness, float* rotmat, float* rotvec, float* betas, float* expr, float* dist_pp, float* dist, int P, hipStream_t s);
+int mhmr_launch_loc(const float* offset, const int* det_y, const int* det_x, int patch, float* loc, int P, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------ profiler
+namespace {
+struct Prof {
+    int kind = -1;
+    std::vector<hipEvent_t> pool;   // start/stop pairs
+    size_t used = 0;
+    double work = 0.0;
+    std::mutex mu;
+} g_prof;
+
+inline hipEvent_t prof_event() {
+    if (g_prof.used == g_prof.pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        g_prof.pool.push_back(e);
+    }
+    return g_prof.pool[g_prof.used++];
+}
+}  // namespace
+
+void prof_begin(int kind, hipStream_t s) {
+    if (g_prof.kind != kind) return;
+    hipEvent_t e = prof_event();
+    if (e) (void)hipEventRecord(e, s);
+}
+void prof_end(int kind, hipStream_t s, double work) {
+    if (g_prof.kind != kind) return;
+    hipEvent_t e = prof_event();
+    if (e) (void)hipEventRecord(e, s);
+    g_prof.work += work;
+}
+
+#define TRY(expr)                 \
+    do {                          \
+        int rc__ = (expr);        \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+extern "C" {
+
+int mhmr_version(void) { return MHMR_VERSION; }
+
+int mhmr_prof_enable(int kind) {
+    if (kind >= PROF_KINDS) return MHMR_ERR_BAD_ARG;
+    g_prof.kind = kind;
+    g_prof.used = 0;
+    g_prof.work = 0.0;
+    return 0;
+}
+
+int mhmr_prof_collect(int* launches, double* total_ms, double* total_work) {
+    double ms = 0.0;
+    const size_t n = g_prof.used / 2;
+    for (size_t i = 0; i < n; ++i) {
+        hipError_t e = hipEventSynchronize(g_prof.pool[2 * i + 1]);
+        if (e != hipSuccess) return (int)e;
+        float t = 0.f;
+        e = hipEventElapsedTime(&t, g_prof.pool[2 * i], g_prof.pool[2 * i + 1]);
+        if (e != hipSuccess) return (int)e;
+        ms += t;
+    }
+    if (launches) *launches = (int)n;
+    if (total_ms) *total_ms = ms;
+    if (total_work) *total_work = g_prof.work;
+    g_prof.used = 0;
+    g_prof.work = 0.0;
+    return 0;
+}
+
+int mhmr_gemm16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, const float* gamma,
+                void* out, int ldo, const float* pos, int Np, int Tp, int H, int Mvalid, int epi, int dtype, void* stream) {
+    GemmArgs g{A, lda, W, ldw, M, N, K, bias, gamma, out, ldo, pos, Np, Tp, H, Mvalid, epi};
+    return mhmr_launch_gemm(g, dtype, (hipStream_t)stream);
+}
+
+int mhmr_attention16(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, void* stream) {
+    return mhmr_launch_attention(qk, vt, out, B, T, Tp, C, H, dtype, (hipStream_t)stream);
+}
+
+int mhmr_layernorm16(const float* in, const float* w, const float* b, void* out16, int rows, int C, float eps, int dtype,
+                     void* stream) {
+    return mhmr_launch_layernorm(in, w, b, out16, rows, C, eps, dtype, (hipStream_t)stream);
+}
+
+int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void* ctx16, int ldctx, void* stream) {
+    if (!d || !x || !feat32 || !ctx16) return MHMR_ERR_BAD_ARG;
+    if (d->S % 14 || d->G * 14 != d->S || d->N != d->G * d->G || d->T != d->N + 1 || d->Tp % 128 || d->Tp < d->T ||
+        d->C != d->H * 64 || d->Kp % 64 || d->Kp < 588 || (d->C != 384 && d->C != 768 && d->C != 1024))
+        return MHMR_ERR_BAD_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int dt = d->dtype, B = d->B, C = d->C, Tp = d->Tp, M = B * Tp;
+    const int Mp = (B * d->N + 127) / 128 * 128;
+    const size_t esz = 2;
+
+    // tokens: patch embedding (im2col + GEMM with bias / pos-embed epilogue), class + padding rows
+    TRY(mhmr_launch_im2col(x, d->a_patch, B, d->S, d->G, d->Kp, dt, s));
+    TRY(mhmr_launch_init_rows(d->resid, d->cls_pos0, B, d->T, Tp, C, s));
+    {
+        GemmArgs g{d->a_patch, d->Kp, d->patch_w, d->Kp, Mp, C, d->Kp, d->patch_b, nullptr, d->resid, C, d->pos, d->N, Tp, d->H,
+                   B * d->N, EPI_PATCH};
+        TRY(mhmr_launch_gemm(g, dt, s));
+    }
+    for (int l = 0; l < d->L; ++l) {
+        const mhmr_vit_block& k = d->blocks[l];
+        // x = x + ls1 * proj(MHSA(norm1(x)))
+        TRY(mhmr_launch_layernorm(d->resid, k.ln1_w, k.ln1_b, d->xn, M, C, 1e-6f, dt, s));
+        {
+            GemmArgs g{d->xn, C, k.qkv_w, C, M, 2 * C, C, k.qkv_b, nullptr, d->qk, 2 * C, nullptr, 0, Tp, d->H, M, EPI_OP16};
+            TRY(mhmr_launch_gemm(g, dt, s));
+            GemmArgs gv{d->xn, C, (const char*)k.qkv_w + (size_t)2 * C * C * esz, C, M, C, C, k.qkv_b + 2 * C, nullptr, d->vt, 0,
+                        nullptr, 0, Tp, d->H, M, EPI_VT};
+            TRY(mhmr_launch_gemm(gv, dt, s));
+        }
+        TRY(mhmr_launch_attention(d->qk, d->vt, d->att, B, d->T, Tp, C, d->H, dt, s));
+        {
+            GemmArgs g{d->att, C, k.proj_w, C, M, C, C, k.proj_b, k.ls1, d->resid, C, nullptr, 0, Tp, d->H, M, EPI_RESID};
+            TRY(mhmr_launch_gemm(g, dt, s));
+        }
+        // x = x + ls2 * fc2(gelu(fc1(norm2(x))))
+        TRY(mhmr_launch_layernorm(d->resid, k.ln2_w, k.ln2_b, d->xn, M, C, 1e-6f, dt, s));
+        {
+            GemmArgs g{d->xn, C, k.fc1_w, C, M, 4 * C, C, k.fc1_b, nullptr, d->hid, 4 * C, nullptr, 0, Tp, d->H, M, EPI_OP16_GELU};
+            TRY(mhmr_launch_gemm(g, dt, s));
+            GemmArgs g2{d->hid, 4 * C, k.fc2_w, 4 * C, M, C, 4 * C, k.fc2_b, k.ls2, d->resid, C, nullptr, 0, Tp, d->H, M, EPI_RESID};
+            TRY(mhmr_launch_gemm(g2, dt, s));
+        }
+    }
+    return mhmr_launch_final_norm(d->resid, d->norm_w, d->norm_b, ctx16, ldctx, feat32, B, d->N, Tp, C, 1e-6f, dt, s);
+}
+
+int mhmr_detect_scores(const void* hid16, int ld, const float* w2, const float* b2, float* scores, int rows, int C, int dtype,
+                       void* stream) {
+    return mhmr_launch_scores(hid16, ld, w2, b2, scores, rows, C, dtype, (hipStream_t)stream);
+}
+int mhmr_detect_count(const float* scores, int B, int G, int nms_kernel, float thr, int* counts, void* stream) {
+    if (nms_kernel < 1 || B <= 0) return MHMR_ERR_BAD_ARG;
+    return mhmr_launch_detect_count(scores, B, G, nms_kernel, thr, counts, (hipStream_t)stream);
+}
+int mhmr_detect_write(const float* scores, int B, int G, int nms_kernel, float thr, const int* base, int* det_b, int* det_y,
+                      int* det_x, float* det_score, void* stream) {
+    if (nms_kernel < 1 || B <= 0) return MHMR_ERR_BAD_ARG;
+    return mhmr_launch_detect_write(scores, B, G, nms_kernel, thr, base, det_b, det_y, det_x, det_score, (hipStream_t)stream);
+}
+int mhmr_camera_embed(const float* K, const float* freq, int B, int G, int patch, float* zK, void* ctx16, int ldctx, int C,
+                      int dtype, void* stream) {
+    return mhmr_launch_camera_embed(K, freq, B, G, patch, zK, ctx16, ldctx, C, dtype, (hipStream_t)stream);
+}
+int mhmr_linear_f32(const float* X, int ldx, const int* row_idx, const float* W, int ldw, const float* bias, const float* R,
+                    int ldr, float* Y, int ldy, int M, int N, int K, int act, void* stream) {
+    return mhmr_launch_linear_f32(X, ldx, row_idx, W, ldw, bias, R, ldr, Y, ldy, M, N, K, act, (hipStream_t)stream);
+}
+int mhmr_layernorm_f32(const float* in, const float* w, const float* b, float* out, int rows, int C, float eps, void* stream) {
+    return mhmr_launch_layernorm_f32(in, w, b, out, rows, C, eps, (hipStream_t)stream);
+}
+
+int mhmr_hph_forward(const mhmr_hph_desc* d, const float* feat32, const float* zK, void* ctx16, const int* det_b,
+                     const int* det_y, const int* det_x, int P, const int* gstart, int ngroups, int nmax, const int* chunks,
+                     int nchunks, const float* K, int B, float* offset, float* loc, float* rotmat, float* rotvec, float* betas,
+                     float* expr, float* dist_pp, float* dist, void* stream) {
+    if (!d || P < 0) return MHMR_ERR_BAD_ARG;
+    if (P == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int C = d->C, dim = d->dim, inner = d->heads * 32, mlp = d->mlp;
+    if (d->Ktok % 16 || d->Kc % 64 || C % 16 || dim % 64 || mlp % 16 || (2 * inner) % 128) return MHMR_ERR_BAD_SHAPE;
+    const int Mctx = (B * d->N + 127) / 128 * 128;
+
+    // queries, mlp_offset input, context rows of the detected cells  (model.py:255-265, 500-517, 541-552)
+    TRY(mhmr_launch_hph_inputs(feat32, zK, det_b, det_y, det_x, d->cq_x, d->cq_y, d->cv_x, d->cv_y, d->init_tail,
+                               318 + d->nb + 3, d->zc, d->token, d->Ktok, ctx16, d->Kc, d->det_row, P, d->G, C, d->dtype, s));
+    // mlp_offset (model.py:258) and loc (272-275)
+    TRY(mhmr_launch_linear_f32(d->zc, C, nullptr, d->off1_w, C, d->off1_b, nullptr, 0, d->t1, C, P, C, C, MHMR_ACT_RELU, s));
+    TRY(mhmr_launch_linear_f32(d->t1, C, nullptr, d->off2_w, C, d->off2_b, nullptr, 0, offset, 2, P, 2, C, MHMR_ACT_NONE, s));
+    TRY(mhmr_launch_loc(offset, det_y, det_x, d->patch, loc, P, s));
+    // token embedding (+ pos_embedding folded into the bias)  (cross_attn_transformer.py:352-357)
+    TRY(mhmr_launch_linear_f32(d->token, d->Ktok, nullptr, d->tok_w, d->Ktok, d->tok_b, nullptr, 0, d->x, dim, P, dim, d->Ktok,
+                               MHMR_ACT_NONE, s));
+    for (int l = 0; l < d->depth; ++l) {
+        const mhmr_hph_layer& L = d->layers[l];
+        // self-attention among the queries of one image
+        TRY(mhmr_launch_layernorm_f32(d->x, L.ln_sa_w, L.ln_sa_b, d->xn, P, dim, 1e-5f, s));
+        TRY(mhmr_launch_linear_f32(d->xn, dim, nullptr, L.to_qkv, dim, nullptr, nullptr, 0, d->t1, 3 * inner, P, 3 * inner, dim,
+                                   MHMR_ACT_NONE, s));
+        TRY(mhmr_launch_hph_self_attn(d->t1, gstart, d->t2, ngroups, nmax, d->heads, s));
+        TRY(mhmr_launch_linear_f32(d->t2, inner, nullptr, L.sa_out_w, inner, L.sa_out_b, d->x, dim, d->x, dim, P, dim, inner,
+                                   MHMR_ACT_NONE, s));
+        // cross-attention over the (un-normalised) per-image context
+        {
+            GemmArgs g{ctx16, d->Kc, L.to_kv16, d->Kc, Mctx, 2 * inner, d->Kc, nullptr, nullptr, d->kv, 2 * inner, nullptr, 0, 128,
+                       1, Mctx, EPI_F32};
+            TRY(mhmr_launch_gemm(g, d->dtype, s));
+        }
+        TRY(mhmr_launch_layernorm_f32(d->x, L.ln_ca_w, L.ln_ca_b, d->xn, P, dim, 1e-5f, s));
+        TRY(mhmr_launch_linear_f32(d->xn, dim, nullptr, L.to_q, dim, nullptr, nullptr, 0, d->t1, inner, P, inner, dim, MHMR_ACT_NONE, s));
+        TRY(mhmr_launch_hph_cross_attn(d->t1, d->kv, chunks, nchunks, d->t2, d->heads, d->N, s));
+        TRY(mhmr_launch_linear_f32(d->t2, inner, nullptr, L.ca_out_w, inner, L.ca_out_b, d->x, dim, d->x, dim, P, dim, inner,
+                                   MHMR_ACT_NONE, s));
+        // feed-forward
+        TRY(mhmr_launch_layernorm_f32(d->x, L.ln_ff_w, L.ln_ff_b, d->xn, P, dim, 1e-5f, s));
+        TRY(mhmr_launch_linear_f32(d->xn, dim, nullptr, L.ff1_w, dim, L.ff1_b, nullptr, 0, d->t1, mlp, P, mlp, dim, MHMR_ACT_GELU, s));
+        TRY(mhmr_launch_linear_f32(d->t1, mlp, nullptr, L.ff2_w, mlp, L.ff2_b, d->x, dim, d->x, dim, P, dim, mlp, MHMR_ACT_NONE, s));
+    }
+    // read-outs + init (model.py:571-575), 6D -> rotmat -> rotvec, distance post-processing
+    TRY(mhmr_launch_linear_f32(d->x, dim, nullptr, d->dec_w, dim, d->dec_b, nullptr, 0, d->dec, d->Ndec, P, d->Ndec, dim, MHMR_ACT_NONE, s));
+    return mhmr_launch_hph_decode(d->dec, d->Ndec, d->nb, K, det_b, d->fn, d->nearness, rotmat, rotvec, betas, expr, dist_pp,
+                                  dist, P, s);
+}
+
+}  // extern "C"

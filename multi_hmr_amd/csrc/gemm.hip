@@ -1,0 +1,214 @@
+// 16-bit-operand GEMM with fused epilogues for the DINOv2 ViT blocks and the heads.
+//
+//   C[m][n] = sum_k A[m][k] * W[n][k]          A: [M,K] activations, W: [N,K] nn.Linear weight (K contiguous)
+//
+// gfx950 structure: 128x128 block tile, BK = 64, 4 waves (2x2), each wave a 64x64 sub-tile as 2x2
+// v_mfma_f32_32x32x16 fragments (fp32 accumulate).  Both operand tiles are staged by
+// global_load_lds_dwordx4 (16 B/lane, no VGPR round trip) into double-buffered LDS with the XOR swizzle
+// applied on the per-lane SOURCE address (the DMA destination is lane-linear), read back conflict-free with
+// ds_read_b128; one barrier per K tile, next tile's DMA in flight under the current tile's 16 MFMAs.
+//
+// Orientation: the MFMA's first operand indexes D's rows (4 consecutive rows per accumulator quad), the second
+// D's columns (one per lane).  For row-major [m][n] outputs the WEIGHT tile is the first operand so every lane
+// owns 4 consecutive n of one m (8/16-byte stores); for the transposed V^T output the ACTIVATION tile is first
+// so every lane owns 4 consecutive tokens of one channel.
+#include "mhmr_common.h"
+#include "mhmr_internal.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * BK * 2;  // 16 KiB per operand tile
+
+template <int DT, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+    typedef typename Op<DT>::T T;
+    typedef typename Op<DT>::V8 V8;
+    typedef typename Op<DT>::V4 V4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A tile | W tile]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    const int nbn = g.N / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % nbn, tm = bid / nbn;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- staging addresses (per thread constant; advance by BK per K tile) ----
+    const int srow = tid >> 3;                                   // 0..31 (+32 per pass)
+    const int schunk = (tid & 7) ^ ((tid >> 4) & 7);             // logical chunk landing at phys chunk tid&7
+    const T* a_src = (const T*)g.A + (size_t)(m0 + srow) * g.lda + schunk * 8;
+    const T* w_src = (const T*)g.W + (size_t)(n0 + srow) * g.ldw + schunk * 8;
+    const size_t a_pass = (size_t)32 * g.lda, w_pass = (size_t)32 * g.ldw;
+
+    auto stage = [&](int kt, int buf) {
+        char* sa = smem + buf * (2 * TILE_BYTES) + w * 1024;
+        char* sw = sa + TILE_BYTES;
+        const T* ap = a_src + kt * BK;
+        const T* wp = w_src + kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(ap + i * a_pass, sa + i * 4096);
+            glds16(wp + i * w_pass, sw + i * 4096);
+        }
+    };
+
+    // ---- fragment read offsets ----
+    constexpr bool ROWMAJOR = (EPI != EPI_VT);
+    // first operand (D rows): W tile for row-major outputs, A tile for V^T; second operand: the other one
+    const int wp_ = w >> 1, wq_ = w & 1;
+    const int p_tile_off = ROWMAJOR ? TILE_BYTES : 0;
+    const int q_tile_off = ROWMAJOR ? 0 : TILE_BYTES;
+    const int fsw = (lane >> 1) & 7;  // ((row >> 1) & 7) for row = 32*s + l31
+    const int p_row = 64 * wp_ + l31, q_row = 64 * wq_ + l31;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nt = g.K / BK;
+    stage(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();  // tile t landed (vmcnt(0) + barrier); everyone is done reading the other buffer
+        if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+        const char* sb = smem + (t & 1) * (2 * TILE_BYTES);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int ph = ((2 * ks + hi) ^ fsw) * 16;
+            V8 pf[2], qf[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                pf[s] = *(const V8*)(sb + p_tile_off + (p_row + 32 * s) * 128 + ph);
+                qf[s] = *(const V8*)(sb + q_tile_off + (q_row + 32 * s) * 128 + ph);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = Op<DT>::mfma32(pf[i], qf[j], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue ----
+    if constexpr (ROWMAJOR) {
+#pragma unroll
+        for (int qj = 0; qj < 2; ++qj) {
+            const int m = m0 + 64 * wq_ + 32 * qj + l31;
+            size_t orow = (size_t)m;
+            const float* posrow = nullptr;
+            if constexpr (EPI == EPI_PATCH) {
+                const int b = m / g.Np, n_in = m - b * g.Np;
+                orow = (size_t)b * g.Tp + 1 + n_in;
+                posrow = g.pos + (size_t)(1 + n_in) * g.N;
+            }
+            if constexpr (EPI == EPI_PATCH) {
+                if (m >= g.Mvalid) continue;
+            }
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int n = n0 + 64 * wp_ + 32 * pi + 8 * rg + 4 * hi;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[pi][qj][4 * rg + e];
+                    if (g.bias) v += *(const f32x4*)(g.bias + n);
+                    if constexpr (EPI == EPI_OP16 || EPI == EPI_OP16_GELU || EPI == EPI_OP16_RELU) {
+                        if constexpr (EPI == EPI_OP16_GELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                        }
+                        if constexpr (EPI == EPI_OP16_RELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        V4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
+                        *(V4*)((T*)g.out + orow * g.ldo + n) = o;
+                    } else if constexpr (EPI == EPI_RESID) {
+                        float* op = (float*)g.out + orow * g.ldo + n;
+                        const f32x4 r = *(const f32x4*)op;
+                        const f32x4 gm = *(const f32x4*)(g.gamma + n);
+                        *(f32x4*)op = r + gm * v;
+                    } else if constexpr (EPI == EPI_PATCH) {
+                        v += *(const f32x4*)(posrow + n);
+                        *(f32x4*)((float*)g.out + orow * g.ldo + n) = v;
+                    } else {  // EPI_F32
+                        *(f32x4*)((float*)g.out + orow * g.ldo + n) = v;
+                    }
+                }
+            }
+        }
+    } else {
+        // V^T: vt[((b*H + h)*64 + d) * Tp + swap23(t)], 4 consecutive tokens per lane (8-byte store)
+        const int b = m0 / g.Tp, t0 = m0 - b * g.Tp;
+#pragma unroll
+        for (int qj = 0; qj < 2; ++qj) {
+            const int n = n0 + 64 * wq_ + 32 * qj + l31;
+            const float bv = g.bias ? g.bias[n] : 0.f;
+            const int h = n >> 6, d = n & 63;
+            T* base = (T*)g.out + ((size_t)(b * g.H + h) * 64 + d) * g.Tp;
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int t = t0 + 64 * wp_ + 32 * pi + 8 * rg + 4 * hi;
+                    const int ts = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);  // swap key bits 2 and 3
+                    V4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (T)(acc[pi][qj][4 * rg + e] + bv);
+                    *(V4*)(base + ts) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int DT>
+int launch_dt(const GemmArgs& g, hipStream_t s) {
+    const int grid = (g.M / BM) * (g.N / BN);
+    const size_t lds = 4 * TILE_BYTES;
+#define MHMR_GEMM_CASE(E)                                                                                   \
+    case E: {                                                                                               \
+        static bool attr_set = false;                                                                       \
+        if (!attr_set) {                                                                                    \
+            (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)lds);                                                            \
+            attr_set = true;                                                                                \
+        }                                                                                                   \
+        hipLaunchKernelGGL((gemm_kernel<DT, E>), dim3(grid), dim3(256), lds, s, g);                         \
+        break;                                                                                              \
+    }
+    switch (g.epi) {
+        MHMR_GEMM_CASE(EPI_OP16)
+        MHMR_GEMM_CASE(EPI_OP16_GELU)
+        MHMR_GEMM_CASE(EPI_OP16_RELU)
+        MHMR_GEMM_CASE(EPI_RESID)
+        MHMR_GEMM_CASE(EPI_PATCH)
+        MHMR_GEMM_CASE(EPI_F32)
+        MHMR_GEMM_CASE(EPI_VT)
+        default:
+            return MHMR_ERR_BAD_ARG;
+    }
+#undef MHMR_GEMM_CASE
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % BM || g.N % BN || g.K % BK) return MHMR_ERR_BAD_SHAPE;
+    if (g.lda % 8 || g.ldw % 8) return MHMR_ERR_BAD_SHAPE;
+    if (g.epi == EPI_VT && (g.Tp % BM || g.N % 64)) return MHMR_ERR_BAD_SHAPE;
+    prof_begin(PROF_GEMM, s);
+    const int rc = dtype == MHMR_DT_F16 ? launch_dt<MHMR_DT_F16>(g, s) : launch_dt<MHMR_DT_BF16>(g, s);
+    prof_end(PROF_GEMM, s, 2.0 * g.M * g.N * g.K);
+    return rc;
+}

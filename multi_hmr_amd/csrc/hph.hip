@@ -1,0 +1,541 @@
+// fp32 kernels of the detection heads and the Human Perception Head (HPH) cross-attention decoder
+// (reference model.py:133-158, 479-593; blocks/cross_attn_transformer.py).  Everything downstream of the
+// backbone features is <1 % of the FLOPs, so it stays in exact fp32: linears run on the fp32-input MFMA
+// (v_mfma_f32_16x16x4_f32 == an fmaf chain), attention over the ragged per-image query groups is done with
+// lanes = queries (self-attention) or lanes = 8 queries x 8 key slices (cross-attention over the N patch
+// tokens) and an online softmax; padded queries of the reference never exist here.
+#include "mhmr_common.h"
+#include "mhmr_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Y[m][n] = act( sum_k X[row(m)][k] * W[n][k] + bias[n] ) (+ R[m][n]);  K % 16 == 0 (callers pad with zeros).
+// One wave = 16 (m) x 32 (n); block = 4 waves along n = 16 x 128.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ X, int ldx, const int* __restrict__ row_idx,
+                                                         const float* __restrict__ W, int ldw, const float* __restrict__ bias,
+                                                         const float* R, int ldr, float* Y, int ldy, int M, int N, int K,
+                                                         int act) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 128 + w * 32;
+    if (n0 >= N) return;
+    int mrow = min(m0 + l15, M - 1);
+    if (row_idx) mrow = row_idx[mrow];
+    const float* xp = X + (size_t)mrow * ldx + 4 * g;
+    const float* wp0 = W + (size_t)min(n0 + l15, N - 1) * ldw + 4 * g;
+    const float* wp1 = W + (size_t)min(n0 + 16 + l15, N - 1) * ldw + 4 * g;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = 0; k < K; k += 16) {
+        const f32x4 xa = *(const f32x4*)(xp + k);
+        const f32x4 w0 = *(const f32x4*)(wp0 + k);
+        const f32x4 w1 = *(const f32x4*)(wp1 + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[e], w0[e], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[e], w1[e], acc1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = n0 + 16 * t + l15;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 4 * g + r;
+            if (m >= M) continue;
+            float v = (t == 0 ? acc0[r] : acc1[r]) + bv;
+            if (act == MHMR_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (act == MHMR_ACT_GELU) v = gelu_erf(v);
+            if (R) v += R[(size_t)m * ldr + n];
+            Y[(size_t)m * ldy + n] = v;
+        }
+    }
+}
+
+// One wave per row, fp32 in / fp32 out, C % 64 == 0, C <= 2048.
+__global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restrict__ in, const float* __restrict__ gw,
+                                                            const float* __restrict__ gb, float* __restrict__ out, int rows,
+                                                            int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* ip = in + (size_t)row * C;
+    float v[32];
+    const int n = C / 64;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+        if (i < n) { v[i] = ip[i * 64 + lane]; s += v[i]; }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+        if (i < n) { v[i] -= mean; q += v[i] * v[i]; }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+        if (i < n) out[(size_t)row * C + i * 64 + lane] = v[i] * rstd * gw[i * 64 + lane] + gb[i * 64 + lane];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Detection: score[m] = clamp(sigmoid(hidden16[m] . w2 + b2), 1e-4, 1-1e-4)   (model.py:135, 641-643)
+// ------------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void score_kernel(const void* __restrict__ hid_, int ld, const float* __restrict__ w2,
+                                                    const float* __restrict__ b2, float* __restrict__ scores, int rows, int C) {
+    typedef typename Op<DT>::T T;
+    typedef typename Op<DT>::V2 V2;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* hp = (const T*)hid_ + (size_t)row * ld;
+    float s = 0.f;
+    for (int c = lane * 2; c < C; c += 128) {
+        const V2 h = *(const V2*)(hp + c);
+        s += (float)h[0] * w2[c] + (float)h[1] * w2[c + 1];
+    }
+    s = wave_sum(s) + b2[0];
+    if (lane == 0) scores[row] = fminf(fmaxf(1.0f / (1.0f + expf(-s)), 1e-4f), 1.0f - 1e-4f);
+}
+
+// NMS (model.py:620-638) + threshold (612-617).  hmax over the k x k window anchored at (y - pad, x - pad),
+// out-of-image = -inf, exactly max_pool2d(stride 1, padding pad) cropped to G x G.  score' = heat * (hmax == heat).
+__device__ __forceinline__ float nms_score(const float* __restrict__ heat, int G, int y, int x, int k, int pad) {
+    const float c = heat[y * G + x];
+    if (k <= 1) return c;
+    float mx = -INFINITY;
+    for (int dy = 0; dy < k; ++dy) {
+        const int yy = y - pad + dy;
+        if (yy < 0 || yy >= G) continue;
+        for (int dx = 0; dx < k; ++dx) {
+            const int xx = x - pad + dx;
+            if (xx < 0 || xx >= G) continue;
+            mx = fmaxf(mx, heat[yy * G + xx]);
+        }
+    }
+    return mx == c ? c : 0.f;
+}
+
+// pass 1: one block per image -> counts[b]
+__global__ __launch_bounds__(256) void detect_count_kernel(const float* __restrict__ scores, int G, int k, int pad, float thr,
+                                                           int* __restrict__ counts) {
+    __shared__ int red[4];
+    const int b = blockIdx.x, N = G * G;
+    const float* heat = scores + (size_t)b * N;
+    int c = 0;
+    for (int n = threadIdx.x; n < N; n += 256) c += nms_score(heat, G, n / G, n % G, k, pad) >= thr ? 1 : 0;
+    c = (int)wave_sum((float)c);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[b] = red[0] + red[1] + red[2] + red[3];
+}
+
+// pass 2: one block per image; ordered ((b, y, x) ascending == torch.where order, model.py:146-149) compaction.
+// base[b] = exclusive prefix of counts (host).  Each thread owns a contiguous run of cells.
+__global__ __launch_bounds__(256) void detect_write_kernel(const float* __restrict__ scores, int G, int k, int pad, float thr,
+                                                           const int* __restrict__ base, int* __restrict__ det_b,
+                                                           int* __restrict__ det_y, int* __restrict__ det_x,
+                                                           float* __restrict__ det_score) {
+    __shared__ int cnt[256];
+    const int b = blockIdx.x, N = G * G, t = threadIdx.x;
+    const float* heat = scores + (size_t)b * N;
+    const int per = (N + 255) / 256, n_lo = min(t * per, N), n_hi = min(n_lo + per, N);
+    int c = 0;
+    for (int n = n_lo; n < n_hi; ++n) c += nms_score(heat, G, n / G, n % G, k, pad) >= thr ? 1 : 0;
+    cnt[t] = c;
+    __syncthreads();
+    int off = base[b];
+    for (int i = 0; i < t; ++i) off += cnt[i];
+    for (int n = n_lo; n < n_hi; ++n) {
+        const float s = nms_score(heat, G, n / G, n % G, k, pad);
+        if (s >= thr) {
+            det_b[off] = b; det_y[off] = n / G; det_x[off] = n % G; det_score[off] = s;
+            ++off;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Camera embedding (model.py:160-187, utils/camera.py:30-48, blocks/camera_embed.py:39-58).
+// ray = K^-1 [i*14+7, j*14+7, 1] with i = ROW index fed as pixel-x, j = COLUMN as pixel-y (reproduced verbatim);
+// z_K = [ray(3), sin(pi*ray_a*f_k) (a*16+k), cos(...)] = 99 channels.  Also writes the 16-bit copy into the
+// cross-attention context operand ctx16[:, C : C+99] and zeros ctx16[:, C+99 : Kc].
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void inv3x3(const float* k, float* o) {
+    const float a = k[0], b = k[1], c = k[2], d = k[3], e = k[4], f = k[5], g = k[6], h = k[7], i = k[8];
+    const float A = e * i - f * h, B = -(d * i - f * g), Cc = d * h - e * g;
+    const float det = a * A + b * B + c * Cc;
+    const float id = 1.0f / det;
+    o[0] = A * id; o[1] = -(b * i - c * h) * id; o[2] = (b * f - c * e) * id;
+    o[3] = B * id; o[4] = (a * i - c * g) * id;  o[5] = -(a * f - c * d) * id;
+    o[6] = Cc * id; o[7] = -(a * h - b * g) * id; o[8] = (a * e - b * d) * id;
+}
+
+template <int DT>
+__global__ __launch_bounds__(128) void camera_embed_kernel(const float* __restrict__ Kmat, const float* __restrict__ freq,
+                                                           int G, int patch, float* __restrict__ zK, void* __restrict__ ctx16_,
+                                                           int Kc, int C) {
+    typedef typename Op<DT>::T T;
+    const int N = G * G;
+    const int row = blockIdx.x;  // b*N + n
+    const int b = row / N, n = row - b * N;
+    const int i = n / G, j = n - i * G;
+    float Ki[9];
+    inv3x3(Kmat + b * 9, Ki);
+    const float px = (float)(i * patch + patch / 2), py = (float)(j * patch + patch / 2);
+    float ray[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) ray[a] = (Ki[a * 3 + 0] * px + Ki[a * 3 + 1] * py + Ki[a * 3 + 2] * 1.0f) * 1.0f;
+    const int t = threadIdx.x;
+    T* cp = (T*)ctx16_ + (size_t)row * Kc + C;
+    const float PI_F = 3.14159265358979323846f;
+    if (t < 99) {
+        float v;
+        if (t < 3) v = ray[t];
+        else {
+            const int u = (t - 3) % 48, a = u / 16, kb = u % 16;
+            const float arg = PI_F * (ray[a] * freq[a * 16 + kb]);
+            v = (t - 3) < 48 ? sinf(arg) : cosf(arg);
+        }
+        zK[(size_t)row * 99 + t] = v;
+        cp[t] = (T)v;
+    } else if (C + t < Kc) {
+        cp[t] = (T)0.f;
+    }
+    // (Kc - C) <= 128 is asserted by the launcher
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// HPH inputs (model.py:255, 263-265, 500-504, 514-517, 541-552)
+//   zc[p]    = feat32[row_p]                                            (mlp_offset input)
+//   token[p] = [ feat32[row_p] | zK[row_p] ] + cq_x[y_p] + cq_y[x_p]  |  init_pose | init_betas | init_cam | 0-pad
+//   ctx16[row_p][0:Cc] = 16-bit( [feat32 | zK][row_p] + cv_x[y_p] + cv_y[x_p] )
+// NB the *_x tables are indexed by the ROW y and *_y by the COLUMN x, as the reference does.
+// ------------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void hph_inputs_kernel(const float* __restrict__ feat32, const float* __restrict__ zK,
+                                                         const int* __restrict__ det_b, const int* __restrict__ det_y,
+                                                         const int* __restrict__ det_x, const float* __restrict__ cq_x,
+                                                         const float* __restrict__ cq_y, const float* __restrict__ cv_x,
+                                                         const float* __restrict__ cv_y, const float* __restrict__ init_tail,
+                                                         int ntail, float* __restrict__ zc, float* __restrict__ token, int Ktok,
+                                                         void* __restrict__ ctx16_, int Kc, int* __restrict__ det_row, int G,
+                                                         int C) {
+    typedef typename Op<DT>::T T;
+    const int p = blockIdx.x, Cc = C + 99;
+    const int b = det_b[p], y = det_y[p], x = det_x[p];
+    const size_t row = (size_t)b * G * G + (size_t)y * G + x;
+    if (threadIdx.x == 0) det_row[p] = (int)row;
+    T* cp = (T*)ctx16_ + row * Kc;
+    for (int c = threadIdx.x; c < Ktok; c += 256) {
+        float tv = 0.f;
+        if (c < Cc) {
+            const float f = c < C ? feat32[row * C + c] : zK[row * 99 + (c - C)];
+            if (c < C) zc[(size_t)p * C + c] = f;
+            tv = f + (cq_x[(size_t)y * Cc + c] + cq_y[(size_t)x * Cc + c]);
+            cp[c] = (T)(f + (cv_x[(size_t)y * Cc + c] + cv_y[(size_t)x * Cc + c]));
+        } else if (c < Cc + ntail) {
+            tv = init_tail[c - Cc];
+        }
+        token[(size_t)p * Ktok + c] = tv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Self-attention over the queries of one image (Attention.forward :129-159, ragged, unmasked).
+// qkv: [P, 3*inner] (q | k | v), head h = columns h*32..h*32+31.  grid (groups, heads, ceil(nmax/64)).
+// lane = one query; keys streamed (wave-uniform addresses), online softmax.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void hph_self_attn_kernel(const float* __restrict__ qkv, const int* __restrict__ gstart,
+                                                           float* __restrict__ out, int inner, float scale) {
+    const int g = blockIdx.x, h = blockIdx.y;
+    const int s0 = gstart[g], n = gstart[g + 1] - s0;
+    const int qi = blockIdx.z * 64 + threadIdx.x;
+    if (blockIdx.z * 64 >= n) return;
+    const bool active = qi < n;
+    const int ld = 3 * inner;
+    const float* qp = qkv + (size_t)(s0 + (active ? qi : 0)) * ld + h * 32;
+    float q[32], o[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) { q[d] = qp[d] * scale; o[d] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    for (int j = 0; j < n; ++j) {
+        const float* kp = qkv + (size_t)(s0 + j) * ld + inner + h * 32;
+        const float* vp = kp + inner;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) s += q[d] * kp[d];
+        const float mn = fmaxf(m, s);
+        const float a = expf(m - mn), pj = expf(s - mn);
+        l = l * a + pj;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] = o[d] * a + pj * vp[d];
+        m = mn;
+    }
+    if (active) {
+        const float inv = 1.0f / l;
+        float* op = out + (size_t)(s0 + qi) * inner + h * 32;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) op[d] = o[d] * inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Cross-attention of the queries of image b over its N context tokens (CrossAttention.forward :185-205).
+// q: [P, inner]; kv: [B*N, 2*inner] (k | v) fp32.  One wave per (chunk of <= 8 queries, head): lane = slice*8 + qi,
+// slice s handles keys j = s (mod 8); the 8 partial (m, l, o) per query are merged with 3 xor-shuffle rounds.
+// chunks: (image b, first query, count) int triples built on the host from the per-image counts.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void hph_cross_attn_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+                                                            const int* __restrict__ chunks, float* __restrict__ out, int inner,
+                                                            int N, float scale) {
+    const int ch = blockIdx.x, h = blockIdx.y;
+    const int b = chunks[3 * ch], q0 = chunks[3 * ch + 1], nq = chunks[3 * ch + 2];
+    const int lane = threadIdx.x, qi = lane & 7, sl = lane >> 3;
+    const bool active = qi < nq;
+    const float* qp = q + (size_t)(q0 + (active ? qi : 0)) * inner + h * 32;
+    float qv[32], o[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) { qv[d] = qp[d] * scale; o[d] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    const int ld = 2 * inner;
+    const float* kbase = kv + (size_t)b * N * ld + h * 32;
+    for (int j = sl; j < N; j += 8) {
+        const float* kp = kbase + (size_t)j * ld;
+        const float* vp = kp + inner;
+        float kk[32];
+#pragma unroll
+        for (int d = 0; d < 32; d += 4) *(f32x4*)(kk + d) = *(const f32x4*)(kp + d);
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) s += qv[d] * kk[d];
+        if (s > m) {  // rare after the first few keys
+            const float a = expf(m - s);
+            l *= a;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) o[d] *= a;
+            m = s;
+        }
+        const float pj = expf(s - m);
+        l += pj;
+#pragma unroll
+        for (int d = 0; d < 32; d += 4) {
+            const f32x4 vv = *(const f32x4*)(vp + d);
+            o[d] += pj * vv[0]; o[d + 1] += pj * vv[1]; o[d + 2] += pj * vv[2]; o[d + 3] += pj * vv[3];
+        }
+    }
+    // merge the 8 key slices (lanes differing in bits 3..5)
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+        const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
+        const float mn = fmaxf(m, m2);
+        const float a1 = (m == -INFINITY) ? 0.f : expf(m - mn), a2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
+        l = l * a1 + l2 * a2;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] = o[d] * a1 + __shfl_xor(o[d], off) * a2;
+        m = mn;
+    }
+    if (active && sl == 0) {
+        const float inv = 1.0f / l;
+        float* op = out + (size_t)(q0 + qi) * inner + h * 32;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) op[d] = o[d] * inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Read-out decode (model.py:571-583, 287-298; utils/humans.py:12-22; roma special_gramschmidt / rotmat_to_rotvec;
+// utils/camera.py:71-90).  dec[p] = [pose6d(318) | betas(nb) | cam(3) | expr(10)] (decoder + init already added).
+// One thread per (person, joint); thread joint 0 also post-processes the distance.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void hph_decode_kernel(const float* __restrict__ dec, int ldd, int nb,
+                                                        const float* __restrict__ Kmat, const int* __restrict__ det_b,
+                                                        float fn, int nearness, float* __restrict__ rotmat,
+                                                        float* __restrict__ rotvec, float* __restrict__ betas,
+                                                        float* __restrict__ expr, float* __restrict__ dist_pp,
+                                                        float* __restrict__ dist) {
+    const int p = blockIdx.x, j = threadIdx.x;
+    const float* dp = dec + (size_t)p * ldd;
+    if (j < 53) {
+        // 6D -> (2,3) -> transpose: first three numbers = column 0, next three = column 1
+        float x0 = dp[6 * j], x1 = dp[6 * j + 1], x2 = dp[6 * j + 2];
+        float y0 = dp[6 * j + 3], y1 = dp[6 * j + 4], y2 = dp[6 * j + 5];
+        const float nx = sqrtf(x0 * x0 + x1 * x1 + x2 * x2);
+        x0 /= nx; x1 /= nx; x2 /= nx;
+        const float dxy = x0 * y0 + x1 * y1 + x2 * y2;
+        y0 -= dxy * x0; y1 -= dxy * x1; y2 -= dxy * x2;
+        const float ny = sqrtf(y0 * y0 + y1 * y1 + y2 * y2);
+        y0 /= ny; y1 /= ny; y2 /= ny;
+        const float z0 = x1 * y2 - x2 * y1, z1 = x2 * y0 - x0 * y2, z2 = x0 * y1 - x1 * y0;
+        float R[9] = {x0, y0, z0, x1, y1, z1, x2, y2, z2};  // columns [x y z]
+        float* rp = rotmat + ((size_t)p * 53 + j) * 9;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) rp[e] = R[e];
+        // rotmat -> unit quaternion (XYZW), branch on the largest of (R00, R11, R22, trace)
+        const float tr = R[0] + R[4] + R[8];
+        float qx, qy, qz, qw;
+        int choice = 0;  // argmax over (R00, R11, R22, trace), first maximal index wins
+        float best = R[0];
+        if (R[4] > best) { best = R[4]; choice = 1; }
+        if (R[8] > best) { best = R[8]; choice = 2; }
+        if (tr > best) { best = tr; choice = 3; }
+        if (choice == 3) {
+            qx = R[7] - R[5]; qy = R[2] - R[6]; qz = R[3] - R[1]; qw = 1.f + tr;
+        } else {
+            const int i = choice, jj = (i + 1) % 3, kk = (jj + 1) % 3;
+            float qq[3];
+            qq[i] = 1.f - tr + 2.f * R[i * 3 + i];
+            qq[jj] = R[jj * 3 + i] + R[i * 3 + jj];
+            qq[kk] = R[kk * 3 + i] + R[i * 3 + kk];
+            qw = R[kk * 3 + jj] - R[jj * 3 + kk];
+            qx = qq[0]; qy = qq[1]; qz = qq[2];
+        }
+        const float qn = sqrtf(qx * qx + qy * qy + qz * qz + qw * qw);
+        qx /= qn; qy /= qn; qz /= qn; qw /= qn;
+        if (qw < 0.f) { qx = -qx; qy = -qy; qz = -qz; qw = -qw; }
+        const float angle = 2.f * atan2f(sqrtf(qx * qx + qy * qy + qz * qz), qw);
+        float sc;
+        if (fabsf(angle) <= 1e-3f) sc = 2.f + angle * angle / 12.f + 7.f * angle * angle * angle * angle / 2880.f;
+        else sc = angle / sinf(angle / 2.f);
+        float* vp = rotvec + ((size_t)p * 53 + j) * 3;
+        vp[0] = sc * qx; vp[1] = sc * qy; vp[2] = sc * qz;
+    }
+    if (j < nb) betas[(size_t)p * nb + j] = dp[318 + j];
+    if (j < 10) expr[(size_t)p * 10 + j] = dp[318 + nb + 3 + j];
+    if (j == 0) {
+        const float d0 = dp[318 + nb];
+        dist_pp[p] = d0;
+        const float focal = Kmat[det_b[p] * 9 + 0];
+        float d = d0 * (focal / fn);
+        if (nearness) d = expf(d) - 1e-10f;
+        dist[p] = fminf(fmaxf(d, 0.f), 50.f);
+    }
+}
+
+// offsets -> loc:  loc = ([x, y] + 0.5 + offset) * patch     (model.py:272-275)
+__global__ void loc_kernel(const float* __restrict__ offset, const int* __restrict__ det_y, const int* __restrict__ det_x,
+                           float patch, float* __restrict__ loc, int P) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    loc[2 * p] = ((float)det_x[p] + 0.5f + offset[2 * p]) * patch;
+    loc[2 * p + 1] = ((float)det_y[p] + 0.5f + offset[2 * p + 1]) * patch;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- launchers
+int mhmr_launch_linear_f32(const float* X, int ldx, const int* row_idx, const float* W, int ldw, const float* bias,
+                           const float* R, int ldr, float* Y, int ldy, int M, int N, int K, int act, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 16 || ldx % 4 || ldw % 4) return MHMR_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(linear_f32_kernel, dim3((N + 127) / 128, (M + 15) / 16), dim3(256), 0, s, X, ldx, row_idx, W, ldw,
+                       bias, R, ldr, Y, ldy, M, N, K, act);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+int mhmr_launch_layernorm_f32(const float* in, const float* w, const float* b, float* out, int rows, int C, float eps,
+                              hipStream_t s) {
+    if (C % 64 || C > 2048 || rows <= 0) return MHMR_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(layernorm_f32_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, in, w, b, out, rows, C, eps);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+int mhmr_launch_scores(const void* hid, int ld, const float* w2, const float* b2, float* scores, int rows, int C, int dtype,
+                       hipStream_t s) {
+    if (C % 128) return MHMR_ERR_BAD_SHAPE;
+    if (dtype == MHMR_DT_F16)
+        hipLaunchKernelGGL((score_kernel<MHMR_DT_F16>), dim3((rows + 3) / 4), dim3(256), 0, s, hid, ld, w2, b2, scores, rows, C);
+    else
+        hipLaunchKernelGGL((score_kernel<MHMR_DT_BF16>), dim3((rows + 3) / 4), dim3(256), 0, s, hid, ld, w2, b2, scores, rows, C);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+static inline int nms_pad(int k) { return (k == 2) ? 1 : (k == 4) ? 2 : (k - 1) / 2; }
+
+int mhmr_launch_detect_count(const float* scores, int B, int G, int nms_kernel, float thr, int* counts, hipStream_t s) {
+    hipLaunchKernelGGL(detect_count_kernel, dim3(B), dim3(256), 0, s, scores, G, nms_kernel, nms_pad(nms_kernel), thr, counts);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+int mhmr_launch_detect_write(const float* scores, int B, int G, int nms_kernel, float thr, const int* base, int* det_b,
+                             int* det_y, int* det_x, float* det_score, hipStream_t s) {
+    hipLaunchKernelGGL(detect_write_kernel, dim3(B), dim3(256), 0, s, scores, G, nms_kernel, nms_pad(nms_kernel), thr, base,
+                       det_b, det_y, det_x, det_score);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+int mhmr_launch_camera_embed(const float* Kmat, const float* freq, int B, int G, int patch, float* zK, void* ctx16, int Kc,
+                             int C, int dtype, hipStream_t s) {
+    if (Kc - C > 128 || Kc - C < 99) return MHMR_ERR_BAD_SHAPE;
+    if (dtype == MHMR_DT_F16)
+        hipLaunchKernelGGL((camera_embed_kernel<MHMR_DT_F16>), dim3(B * G * G), dim3(128), 0, s, Kmat, freq, G, patch, zK, ctx16, Kc, C);
+    else
+        hipLaunchKernelGGL((camera_embed_kernel<MHMR_DT_BF16>), dim3(B * G * G), dim3(128), 0, s, Kmat, freq, G, patch, zK, ctx16, Kc, C);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+int mhmr_launch_hph_inputs(const float* feat32, const float* zK, const int* det_b, const int* det_y, const int* det_x,
+                           const float* cq_x, const float* cq_y, const float* cv_x, const float* cv_y, const float* init_tail,
+                           int ntail, float* zc, float* token, int Ktok, void* ctx16, int Kc, int* det_row, int P, int G, int C,
+                           int dtype, hipStream_t s) {
+    if (P <= 0) return 0;
+    if (dtype == MHMR_DT_F16)
+        hipLaunchKernelGGL((hph_inputs_kernel<MHMR_DT_F16>), dim3(P), dim3(256), 0, s, feat32, zK, det_b, det_y, det_x, cq_x, cq_y,
+                           cv_x, cv_y, init_tail, ntail, zc, token, Ktok, ctx16, Kc, det_row, G, C);
+    else
+        hipLaunchKernelGGL((hph_inputs_kernel<MHMR_DT_BF16>), dim3(P), dim3(256), 0, s, feat32, zK, det_b, det_y, det_x, cq_x, cq_y,
+                           cv_x, cv_y, init_tail, ntail, zc, token, Ktok, ctx16, Kc, det_row, G, C);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+int mhmr_launch_hph_self_attn(const float* qkv, const int* gstart, float* out, int ngroups, int nmax, int heads,
+                              hipStream_t s) {
+    if (ngroups <= 0) return 0;
+    const int inner = heads * 32;
+    hipLaunchKernelGGL(hph_self_attn_kernel, dim3(ngroups, heads, (nmax + 63) / 64), dim3(64), 0, s, qkv, gstart, out, inner,
+                       0.17677669529663688110f);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+int mhmr_launch_hph_cross_attn(const float* q, const float* kv, const int* chunks, int nchunks, float* out, int heads, int N,
+                               hipStream_t s) {
+    if (nchunks <= 0) return 0;
+    hipLaunchKernelGGL(hph_cross_attn_kernel, dim3(nchunks, heads), dim3(64), 0, s, q, kv, chunks, out, heads * 32, N,
+                       0.17677669529663688110f);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+int mhmr_launch_hph_decode(const float* dec, int ldd, int nb, const float* Kmat, const int* det_b, float fn, int nearness,
+                           float* rotmat, float* rotvec, float* betas, float* expr, float* dist_pp, float* dist, int P,
+                           hipStream_t s) {
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(hph_decode_kernel, dim3(P), dim3(64), 0, s, dec, ldd, nb, Kmat, det_b, fn, nearness, rotmat, rotvec,
+                       betas, expr, dist_pp, dist);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+int mhmr_launch_loc(const float* offset, const int* det_y, const int* det_x, int patch, float* loc, int P, hipStream_t s) {
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(loc_kernel, dim3((P + 127) / 128), dim3(128), 0, s, offset, det_y, det_x, (float)patch, loc, P);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,152 @@
+// HBM-bound helper kernels of the ViT backbone: im2col patchify (fp32 image -> 16-bit GEMM operand), class /
+// padding row initialisation, LayerNorm (fp32 residual stream -> 16-bit GEMM operand), and the final LayerNorm
+// that emits the patch features both as fp32 and as the 16-bit cross-attention context operand.
+#include "mhmr_common.h"
+#include "mhmr_internal.h"
+
+namespace {
+
+// a_patch[m = (b*G + gy)*G + gx][k = c*196 + py*14 + px] = x[b][c][gy*14+py][gx*14+px]; k in [588, Kp) = 0.
+// One thread = 8 consecutive k of one patch (one 16-byte store).
+template <int DT>
+__global__ void im2col_kernel(const float* __restrict__ x, void* __restrict__ a_, int B, int S, int G, int Kp) {
+    typedef typename Op<DT>::T T;
+    typedef typename Op<DT>::V8 V8;
+    const int kc = Kp / 8;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * G * G * kc;
+    if (gid >= total) return;
+    const int c8 = (int)(gid % kc);
+    const long long m = gid / kc;
+    const int gx = (int)(m % G), gy = (int)((m / G) % G), b = (int)(m / ((long long)G * G));
+    V8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = c8 * 8 + e;
+        float f = 0.f;
+        if (k < 588) {
+            const int c = k / 196, rem = k - c * 196, py = rem / 14, px = rem - py * 14;
+            f = x[(((size_t)b * 3 + c) * S + gy * 14 + py) * S + gx * 14 + px];
+        }
+        v[e] = (T)f;
+    }
+    *(V8*)((T*)a_ + (size_t)m * Kp + c8 * 8) = v;
+}
+
+// resid[b*Tp + 0][:] = cls_token + pos[0];  resid[b*Tp + t][:] = 0 for t in [T, Tp)
+__global__ void init_rows_kernel(float* __restrict__ resid, const float* __restrict__ cls_pos0, int B, int T, int Tp, int C) {
+    const int rows_per_img = 1 + (Tp - T);
+    const int r = blockIdx.x;  // 0 .. B*rows_per_img
+    const int b = r / rows_per_img, i = r - b * rows_per_img;
+    const int t = i == 0 ? 0 : T + i - 1;
+    float* dst = resid + ((size_t)b * Tp + t) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) dst[c] = i == 0 ? cls_pos0[c] : 0.f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One wave per row; NP = C / 128 float2 per lane.  Two-pass (mean, then centred variance) in registers.
+template <int DT, int NP, bool FINAL>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, const float* __restrict__ gw,
+                                                        const float* __restrict__ gb, void* __restrict__ out16_, int ld16,
+                                                        float* __restrict__ out32, int rows, int Np, int Tp, float eps) {
+    typedef typename Op<DT>::T T;
+    typedef typename Op<DT>::V2 V2;
+    constexpr int C = NP * 128;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    size_t in_row = row, out_row = row;
+    if constexpr (FINAL) {  // row = b*Np + n  reads token n+1 of image b
+        const int b = row / Np, n = row - b * Np;
+        in_row = (size_t)b * Tp + 1 + n;
+    }
+    const float* ip = in + in_row * C;
+    f32x2 v[NP];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        v[i] = *(const f32x2*)(ip + (i * 64 + lane) * 2);
+        s += v[i][0] + v[i][1];
+    }
+    const float mean = wave_sum(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        v[i][0] -= mean;
+        v[i][1] -= mean;
+        q += v[i][0] * v[i][0] + v[i][1] * v[i][1];
+    }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + eps);
+    T* o16 = (T*)out16_ + out_row * ld16;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int c = (i * 64 + lane) * 2;
+        const f32x2 w = *(const f32x2*)(gw + c), bb = *(const f32x2*)(gb + c);
+        f32x2 y;
+        y[0] = v[i][0] * rstd * w[0] + bb[0];
+        y[1] = v[i][1] * rstd * w[1] + bb[1];
+        V2 h;
+        h[0] = (T)y[0];
+        h[1] = (T)y[1];
+        *(V2*)(o16 + c) = h;
+        if constexpr (FINAL) *(f32x2*)(out32 + out_row * C + c) = y;
+    }
+}
+
+template <int DT, bool FINAL>
+int launch_ln(const float* in, const float* w, const float* b, void* out16, int ld16, float* out32, int rows, int C,
+              int Np, int Tp, float eps, hipStream_t s) {
+    const int grid = (rows + 3) / 4;
+#define LN_CASE(NPV)                                                                                                     \
+    case NPV * 128:                                                                                                      \
+        hipLaunchKernelGGL((layernorm_kernel<DT, NPV, FINAL>), dim3(grid), dim3(256), 0, s, in, w, b, out16, ld16, out32, \
+                           rows, Np, Tp, eps);                                                                           \
+        break;
+    switch (C) {
+        LN_CASE(3)
+        LN_CASE(6)
+        LN_CASE(8)
+        default:
+            return MHMR_ERR_BAD_SHAPE;
+    }
+#undef LN_CASE
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+int mhmr_launch_im2col(const float* x, void* a, int B, int S, int G, int Kp, int dtype, hipStream_t s) {
+    const long long total = (long long)B * G * G * (Kp / 8);
+    const int grid = (int)((total + 255) / 256);
+    if (dtype == MHMR_DT_F16)
+        hipLaunchKernelGGL((im2col_kernel<MHMR_DT_F16>), dim3(grid), dim3(256), 0, s, x, a, B, S, G, Kp);
+    else
+        hipLaunchKernelGGL((im2col_kernel<MHMR_DT_BF16>), dim3(grid), dim3(256), 0, s, x, a, B, S, G, Kp);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+int mhmr_launch_init_rows(float* resid, const float* cls_pos0, int B, int T, int Tp, int C, hipStream_t s) {
+    hipLaunchKernelGGL(init_rows_kernel, dim3(B * (1 + Tp - T)), dim3(256), 0, s, resid, cls_pos0, B, T, Tp, C);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+int mhmr_launch_layernorm(const float* in, const float* w, const float* b, void* out16, int rows, int C, float eps,
+                          int dtype, hipStream_t s) {
+    return dtype == MHMR_DT_F16 ? launch_ln<MHMR_DT_F16, false>(in, w, b, out16, C, nullptr, rows, C, 0, 0, eps, s)
+                                : launch_ln<MHMR_DT_BF16, false>(in, w, b, out16, C, nullptr, rows, C, 0, 0, eps, s);
+}
+
+int mhmr_launch_final_norm(const float* resid, const float* w, const float* b, void* ctx16, int ldctx, float* feat32,
+                           int B, int Np, int Tp, int C, float eps, int dtype, hipStream_t s) {
+    return dtype == MHMR_DT_F16
+               ? launch_ln<MHMR_DT_F16, true>(resid, w, b, ctx16, ldctx, feat32, B * Np, C, Np, Tp, eps, s)
+               : launch_ln<MHMR_DT_BF16, true>(resid, w, b, ctx16, ldctx, feat32, B * Np, C, Np, Tp, eps, s);
+}

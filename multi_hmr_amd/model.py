@@ -1,0 +1,524 @@
+"""Drop-in for the reference ``model.Model`` (naver/multi-hmr model.py:30-349) on MI355X.
+
+Same constructor signature (extra kwargs swallowed, model.py:33-50), same ``nn.Module`` protocol and
+``state_dict`` key names, same ``forward`` signature and return values
+(model.py:205-349) -- but ``forward`` is a sequence of calls into ``libmhmr.so`` (hand-written gfx950 HIP
+kernels behind the C ABI of include/mhmr.h).  PyTorch only owns device memory and the stream.  There is no
+CPU / eager fallback: without the library, or on a non-GPU tensor, ``forward`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib, packing
+from .packing import roundup
+from .synthetic import SMPLX_JOINT_NAMES, VIT_CFG
+
+PATCH = 14
+SMPLX_DIR = "models"                           # reference utils/constants.py:7
+MEAN_PARAMS = "models/smpl_mean_params.npz"    # reference utils/constants.py:8
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Parameter holders: plain nn.Modules that only exist to give state_dict() the reference's key names.
+# ------------------------------------------------------------------------------------------------------------
+class _Holder(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder; compute happens in libmhmr.so")
+
+
+class _LayerScale(_Holder):
+    def __init__(self, dim):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(dim))
+
+
+class _VitAttn(_Holder):
+    def __init__(self, dim):
+        super().__init__()
+        self.qkv = nn.Linear(dim, 3 * dim)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _VitMlp(_Holder):
+    def __init__(self, dim):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, 4 * dim)
+        self.fc2 = nn.Linear(4 * dim, dim)
+
+
+class _VitBlock(_Holder):
+    def __init__(self, dim):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _VitAttn(dim)
+        self.ls1 = _LayerScale(dim)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _VitMlp(dim)
+        self.ls2 = _LayerScale(dim)
+
+
+class _PatchEmbed(_Holder):
+    def __init__(self, dim):
+        super().__init__()
+        self.proj = nn.Conv2d(3, dim, kernel_size=PATCH, stride=PATCH)
+
+
+class _Encoder(_Holder):
+    """Key names of torch.hub dinov2_vit{s,b,l}14 (reference blocks/dinov2.py:12)."""
+
+    def __init__(self, embed_dim, depth, num_heads):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.patch_size = embed_dim, num_heads, PATCH
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, 1 + 37 * 37, embed_dim))
+        self.mask_token = nn.Parameter(torch.zeros(1, embed_dim))
+        self.patch_embed = _PatchEmbed(embed_dim)
+        self.blocks = nn.ModuleList([_VitBlock(embed_dim) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        nn.init.normal_(self.cls_token, std=1e-6)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                nn.init.zeros_(m.bias)
+
+
+class Dinov2Backbone(_Holder):
+    """Reference blocks/dinov2.py:8-26 (name, encoder, patch_size, embed_dim attributes)."""
+
+    def __init__(self, name="dinov2_vitb14", pretrained=False, depth_override=None):
+        super().__init__()
+        if pretrained:
+            raise RuntimeError("pretrained_backbone=True needs torch.hub (network); load a checkpoint state_dict instead")
+        cfg = dict(VIT_CFG[name])
+        if depth_override is not None:
+            cfg["depth"] = depth_override
+        self.name = name
+        self.encoder = _Encoder(**cfg)
+        self.patch_size, self.embed_dim = PATCH, cfg["embed_dim"]
+
+
+class _Fn(_Holder):
+    pass
+
+
+class _PreNorm(_Holder):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fn = fn
+
+
+def _sa(dim, inner):
+    f = _Fn()
+    f.to_qkv = nn.Linear(dim, inner * 3, bias=False)
+    f.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(0.0))
+    return f
+
+
+def _ca(dim, ctx, inner):
+    f = _Fn()
+    f.to_kv = nn.Linear(ctx, inner * 2, bias=False)
+    f.to_q = nn.Linear(dim, inner, bias=False)
+    f.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(0.0))
+    return f
+
+
+def _ff(dim, hidden):
+    f = _Fn()
+    f.net = nn.Sequential(nn.Linear(dim, hidden), nn.GELU(), nn.Dropout(0.0), nn.Linear(hidden, dim), nn.Dropout(0.0))
+    return f
+
+
+class _CrossAttnStack(_Holder):
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, context_dim):
+        super().__init__()
+        inner = heads * dim_head
+        self.layers = nn.ModuleList([nn.ModuleList([_PreNorm(dim, _sa(dim, inner)), _PreNorm(dim, _ca(dim, context_dim, inner)),
+                                                    _PreNorm(dim, _ff(dim, mlp_dim))]) for _ in range(depth)])
+
+
+class _TransformerDecoder(_Holder):
+    """Key names of blocks/cross_attn_transformer.py:302-359."""
+
+    def __init__(self, token_dim, dim, depth, heads, mlp_dim, dim_head, context_dim):
+        super().__init__()
+        self.to_token_embedding = nn.Linear(token_dim, dim)
+        self.pos_embedding = nn.Parameter(torch.randn(1, 1, dim))
+        self.transformer = _CrossAttnStack(dim, depth, heads, dim_head, mlp_dim, context_dim)
+
+
+class HPH(_Holder):
+    """Parameters / buffers of the reference HPH (model.py:352-477)."""
+
+    def __init__(self, context_dim, dim, depth, heads, mlp_dim, dim_head, at_token_res, num_betas, mean_params):
+        super().__init__()
+        assert num_betas in (10, 11) and dim_head == 32
+        self.num_betas, self.res, self.depth, self.heads = num_betas, at_token_res, (depth,), (heads,)
+        self.npose = 6 * 53
+        self.transformer = _TransformerDecoder(self.npose + num_betas + 3 + context_dim, dim, depth, heads, mlp_dim, dim_head, context_dim)
+        self.decpose, self.decshape = nn.Linear(dim, self.npose), nn.Linear(dim, num_betas)
+        self.deccam, self.decexpression = nn.Linear(dim, 3), nn.Linear(dim, 10)
+        # set_smpl_init (model.py:440-477)
+        init_body_pose = torch.eye(3).reshape(1, 3, 3).repeat(53, 1, 1)[:, :, :2].flatten(1).reshape(1, -1)
+        init_body_pose[:, : 24 * 6] = torch.from_numpy(np.asarray(mean_params["pose"][:], dtype=np.float32)).float()
+        init_betas = torch.from_numpy(np.asarray(mean_params["shape"], dtype=np.float32)).unsqueeze(0)
+        init_cam = torch.from_numpy(np.asarray(mean_params["cam"], dtype=np.float32)).unsqueeze(0)
+        init_betas_kid = torch.cat([init_betas, torch.zeros_like(init_betas[:, [0]])], 1)
+        init_expression = 0.0 * init_betas.clone()
+        if num_betas == 11:
+            init_betas = torch.cat([init_betas, torch.zeros_like(init_betas[:, :1])], 1)
+        for n, v in (("init_body_pose", init_body_pose), ("init_betas", init_betas), ("init_betas_kid", init_betas_kid),
+                     ("init_cam", init_cam), ("init_expression", init_expression)):
+            self.register_buffer(n, v)
+        # init_learned_queries (model.py:424-438)
+        for n in ("cross_queries_x", "cross_queries_y", "cross_values_x", "cross_values_y"):
+            p = nn.Parameter(torch.zeros(at_token_res, context_dim))
+            nn.init.normal_(p, std=0.2)
+            setattr(self, n, p)
+
+
+class _BodyModel:
+    """What callers read from ``smpl_layer[...].bm_x`` (demo.py:310: ``.faces``)."""
+
+    def __init__(self, faces):
+        self.faces = faces
+
+
+class SMPL_Layer(_Holder):
+    """Reference blocks/smpl_layer.py:18-45 attributes; the arithmetic lives in lbs.hip."""
+
+    def __init__(self, data, type="smplx", gender="neutral", num_betas=10, kid=False, person_center=None):
+        super().__init__()
+        assert type == "smplx"
+        self.type, self.kid, self.num_betas = type, kid, num_betas
+        self.joint_names = list(SMPLX_JOINT_NAMES)
+        self.person_center = person_center
+        self.person_center_idx = self.joint_names.index(person_center) if person_center is not None else None
+        self.bm_x = _BodyModel(np.asarray(data["f"], dtype=np.int64))
+
+
+def _load_smplx_data(explicit):
+    if explicit is not None:
+        return explicit
+    path = os.path.join(SMPLX_DIR, "smplx", "SMPLX_NEUTRAL.npz")
+    if not os.path.isfile(path):
+        raise FileNotFoundError(f"{path} not found (reference blocks/smpl_layer.py:38 loads it through smplx.create); "
+                                "pass smplx_data=<dict with the SMPLX_NEUTRAL.npz arrays> to Model(...)")
+    return dict(np.load(path, allow_pickle=True))
+
+
+def _load_mean_params(explicit):
+    if explicit is not None:
+        return explicit
+    if not os.path.isfile(MEAN_PARAMS):
+        raise FileNotFoundError(f"{MEAN_PARAMS} not found (reference model.py:442); pass mean_params=<dict pose/shape/cam>")
+    return dict(np.load(MEAN_PARAMS))
+
+
+class Model(nn.Module):
+    """A ViT backbone followed by the HPH head and the SMPL-X layer, on hand-written gfx950 kernels."""
+
+    def __init__(self, backbone="dinov2_vitb14", pretrained_backbone=False, img_size=896, camera_embedding="geometric",
+                 camera_embedding_num_bands=16, camera_embedding_max_resolution=64, nearness=True, xat_depth=2,
+                 xat_num_heads=8, dict_smpl_layer=None, person_center="head", clip_dist=True, num_betas=10, *args, **kwargs):
+        super().__init__()
+        if isinstance(img_size, (list, tuple)):
+            img_size = img_size[0]
+        self.img_size, self.nearness, self.clip_dist = img_size, nearness, (clip_dist,)
+        self.xat_depth, self.xat_num_heads, self.num_betas = xat_depth, xat_num_heads, num_betas
+        self.precision = kwargs.get("precision", os.environ.get("MHMR_PRECISION", "f16"))
+        if self.precision not in packing.OP_DTYPES:
+            raise ValueError(f"precision must be one of {list(packing.OP_DTYPES)}")
+        self.backbone = Dinov2Backbone(backbone, pretrained=pretrained_backbone, depth_override=kwargs.get("backbone_depth"))
+        self.embed_dim, self.patch_size = self.backbone.embed_dim, self.backbone.patch_size
+        assert self.img_size % self.patch_size == 0, "Invalid img size"
+        self.fovn = 60
+        self.camera_embedding = camera_embedding
+        if camera_embedding != "geometric":
+            raise NotImplementedError("Only geometric camera embedding is implemented")
+        if camera_embedding_num_bands != 16 or camera_embedding_max_resolution != 64:
+            raise NotImplementedError("camera embedding kernel is built for 16 bands / max resolution 64 (all released checkpoints)")
+        self.camera_embed_dim = 3 + 2 * 3 * camera_embedding_num_bands   # 99
+        self.mlp_classif = nn.Sequential(nn.Linear(self.embed_dim, self.embed_dim), nn.ReLU(), nn.Linear(self.embed_dim, 1))
+        self.mlp_offset = nn.Sequential(nn.Linear(self.embed_dim, self.embed_dim), nn.ReLU(), nn.Linear(self.embed_dim, 2))
+        self.nrot = 53
+        self._smplx_data = _load_smplx_data(kwargs.get("smplx_data"))
+        self.smpl_layer = nn.ModuleDict({f"neutral_{nb}": SMPL_Layer(self._smplx_data, num_betas=nb, person_center=person_center)
+                                         for nb in (10, 11)})
+        self.x_attention_head = HPH(context_dim=self.embed_dim + self.camera_embed_dim, dim=1024, depth=xat_depth,
+                                    heads=xat_num_heads, mlp_dim=1024, dim_head=32, at_token_res=img_size // PATCH,
+                                    num_betas=num_betas, mean_params=_load_mean_params(kwargs.get("mean_params")))
+        self._packed = None      # (device, precision) -> tensors + descriptors
+        self._ws = {}            # batch size -> workspaces
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    # -------------------------------------------------------------------------------------------------- packing
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        self._packed = None
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def _apply(self, fn, *a, **k):
+        self._packed, self._ws = None, {}
+        return super()._apply(fn, *a, **k)
+
+    def repack(self):
+        """Call after mutating parameters in place (load_state_dict / .to() do it automatically)."""
+        self._packed, self._ws = None, {}
+
+    def _pack(self, device):
+        dt_id, tdt = packing.OP_DTYPES[self.precision]
+        enc = self.backbone.encoder
+        C, H, L = enc.embed_dim, enc.num_heads, len(enc.blocks)
+        S, G = self.img_size, self.img_size // PATCH
+        N, T = G * G, G * G + 1
+        f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        op = lambda t: t.detach().to(device=device, dtype=torch.float32).to(tdt).contiguous()
+        keep = []      # tensors referenced by raw pointers in the descriptors
+
+        def k(t):
+            keep.append(t)
+            return t.data_ptr()
+
+        P = {"dt_id": dt_id, "tdt": tdt, "C": C, "H": H, "L": L, "G": G, "N": N, "T": T, "Tp": roundup(T, 128), "Kp": 640}
+        pos = torch.from_numpy(packing.interpolate_pos_embed(enc.pos_embed.detach().float().cpu().numpy(), G)).to(device)
+        cls_pos0 = f32(enc.cls_token.reshape(-1)) + pos[0]
+        pw = torch.zeros(C, P["Kp"], dtype=torch.float32, device=device)
+        pw[:, :588] = f32(enc.patch_embed.proj.weight).reshape(C, 588)
+        blocks = (_lib.VitBlock * L)()
+        for i, b in enumerate(enc.blocks):
+            blk = blocks[i]
+            blk.ln1_w, blk.ln1_b = k(f32(b.norm1.weight)), k(f32(b.norm1.bias))
+            blk.qkv_w, blk.qkv_b = k(op(b.attn.qkv.weight)), k(f32(b.attn.qkv.bias))
+            blk.proj_w, blk.proj_b, blk.ls1 = k(op(b.attn.proj.weight)), k(f32(b.attn.proj.bias)), k(f32(b.ls1.gamma))
+            blk.ln2_w, blk.ln2_b = k(f32(b.norm2.weight)), k(f32(b.norm2.bias))
+            blk.fc1_w, blk.fc1_b = k(op(b.mlp.fc1.weight)), k(f32(b.mlp.fc1.bias))
+            blk.fc2_w, blk.fc2_b, blk.ls2 = k(op(b.mlp.fc2.weight)), k(f32(b.mlp.fc2.bias)), k(f32(b.ls2.gamma))
+        P["vit"] = dict(blocks=blocks, patch_w=k(pw.to(tdt).contiguous()), patch_b=k(f32(enc.patch_embed.proj.bias)),
+                        cls_pos0=k(cls_pos0.contiguous()), pos=k(pos.contiguous()), norm_w=k(f32(enc.norm.weight)),
+                        norm_b=k(f32(enc.norm.bias)))
+
+        # heads
+        Cc = C + 99
+        Kc = roundup(Cc, 64)
+        P["Cc"], P["Kc"] = Cc, Kc
+        P["cls0_w"], P["cls0_b"] = op(self.mlp_classif[0].weight), f32(self.mlp_classif[0].bias)
+        P["cls2_w"], P["cls2_b"] = f32(self.mlp_classif[2].weight.reshape(-1)), f32(self.mlp_classif[2].bias)
+        P["freq"] = torch.stack([torch.linspace(1.0, 64 / 2, 16) for _ in range(3)]).to(device).contiguous()
+
+        # HPH
+        hp = self.x_attention_head
+        heads, depth, dim, mlp, nb = self.xat_num_heads, self.xat_depth, 1024, 1024, self.num_betas
+        inner = 32 * heads
+        n_kv = roundup(2 * inner, 128)
+        Ktok = roundup(Cc + 318 + nb + 3, 16)
+        tok_w = torch.zeros(dim, Ktok, device=device)
+        tok_w[:, : Cc + 321 + nb] = f32(hp.transformer.to_token_embedding.weight)
+        tok_b = f32(hp.transformer.to_token_embedding.bias) + f32(hp.transformer.pos_embedding[0, 0])
+        layers = (_lib.HphLayer * depth)()
+        for l, (sa, ca, ff) in enumerate(hp.transformer.transformer.layers):
+            y = layers[l]
+            y.ln_sa_w, y.ln_sa_b, y.to_qkv = k(f32(sa.norm.weight)), k(f32(sa.norm.bias)), k(f32(sa.fn.to_qkv.weight))
+            y.sa_out_w, y.sa_out_b = k(f32(sa.fn.to_out[0].weight)), k(f32(sa.fn.to_out[0].bias))
+            y.ln_ca_w, y.ln_ca_b = k(f32(ca.norm.weight)), k(f32(ca.norm.bias))
+            kvw = torch.zeros(n_kv, Kc, device=device)
+            kvw[: 2 * inner, :Cc] = f32(ca.fn.to_kv.weight)
+            y.to_kv16, y.to_q = k(kvw.to(tdt).contiguous()), k(f32(ca.fn.to_q.weight))
+            y.ca_out_w, y.ca_out_b = k(f32(ca.fn.to_out[0].weight)), k(f32(ca.fn.to_out[0].bias))
+            y.ln_ff_w, y.ln_ff_b = k(f32(ff.norm.weight)), k(f32(ff.norm.bias))
+            y.ff1_w, y.ff1_b = k(f32(ff.fn.net[0].weight)), k(f32(ff.fn.net[0].bias))
+            y.ff2_w, y.ff2_b = k(f32(ff.fn.net[3].weight)), k(f32(ff.fn.net[3].bias))
+        dec_w = torch.cat([f32(m.weight) for m in (hp.decpose, hp.decshape, hp.deccam, hp.decexpression)], 0).contiguous()
+        dec_b = (torch.cat([f32(m.bias) for m in (hp.decpose, hp.decshape, hp.deccam, hp.decexpression)], 0) +
+                 torch.cat([f32(hp.init_body_pose[0]), f32(hp.init_betas[0]), f32(hp.init_cam[0]), f32(hp.init_expression[0])], 0))
+        init_tail = torch.cat([f32(hp.init_body_pose[0]), f32(hp.init_betas[0]), f32(hp.init_cam[0])], 0).contiguous()
+        P["hph"] = dict(layers=layers, heads=heads, depth=depth, dim=dim, mlp=mlp, nb=nb, inner=inner, n_kv=n_kv, Ktok=Ktok,
+                        Ndec=318 + nb + 13,
+                        off1_w=k(f32(self.mlp_offset[0].weight)), off1_b=k(f32(self.mlp_offset[0].bias)),
+                        off2_w=k(f32(self.mlp_offset[2].weight)), off2_b=k(f32(self.mlp_offset[2].bias)),
+                        cq_x=k(f32(hp.cross_queries_x)), cq_y=k(f32(hp.cross_queries_y)), cv_x=k(f32(hp.cross_values_x)),
+                        cv_y=k(f32(hp.cross_values_y)), init_tail=k(init_tail), tok_w=k(tok_w.contiguous()), tok_b=k(tok_b.contiguous()),
+                        dec_w=k(dec_w), dec_b=k(dec_b.contiguous()))
+        assert n_kv == 2 * inner, "xat_num_heads must be even (to_kv rows are tiled by 128)"
+
+        # SMPL-X
+        layer = self.smpl_layer[f"neutral_{nb}"]
+        P["lbs"] = packing.pack_smplx(self._smplx_data, nb, device, layer.person_center_idx if layer.person_center_idx is not None else 15)
+        P["lbs_struct"] = packing.lbs_consts_struct(P["lbs"])
+        P["keep"] = keep
+        P["device"] = device
+        self._packed = P
+        return P
+
+    def _workspace(self, P, B):
+        ws = self._ws.get(B)
+        if ws is not None:
+            return ws
+        dev, tdt = P["device"], P["tdt"]
+        C, N, Tp, H = P["C"], P["N"], P["Tp"], P["H"]
+        Mp = roundup(B * N, 128)
+        z = lambda *s, dtype=tdt: torch.zeros(*s, dtype=dtype, device=dev)
+        ws = dict(a_patch=z(Mp, P["Kp"]), resid=z(B * Tp, C, dtype=torch.float32), xn=z(B * Tp, C), qk=z(B * Tp, 2 * C),
+                  vt=z(B * H * 64, Tp), att=z(B * Tp, C), hid=z(B * Tp, 4 * C), feat32=z(B * N, C, dtype=torch.float32),
+                  ctx16=z(Mp, P["Kc"]), zK=z(B * N, 99, dtype=torch.float32), scores=z(B * N, dtype=torch.float32),
+                  counts=z(B, dtype=torch.int32), kv=z(Mp, P["hph"]["n_kv"], dtype=torch.float32))
+        v = P["vit"]
+        d = _lib.VitDesc()
+        d.dtype, d.B, d.S, d.C, d.H, d.L = P["dt_id"], B, self.img_size, C, H, P["L"]
+        d.G, d.N, d.T, d.Tp, d.Kp = P["G"], N, P["T"], Tp, P["Kp"]
+        d.patch_w, d.patch_b, d.cls_pos0, d.pos = v["patch_w"], v["patch_b"], v["cls_pos0"], v["pos"]
+        d.blocks = C_cast_blocks(v["blocks"])
+        d.norm_w, d.norm_b = v["norm_w"], v["norm_b"]
+        for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid"):
+            setattr(d, n, ws[n].data_ptr())
+        ws["vit_desc"] = d
+        self._ws[B] = ws
+        return ws
+
+    # -------------------------------------------------------------------------------------------------- forward
+    def backbone_features(self, x):
+        """[B,3,S,S] -> [B,N,C] fp32 patch features (reference blocks/dinov2.py:16-26), as a view of the workspace."""
+        P, ws, stream = self._prepare(x)
+        L = _lib.lib()
+        _lib.check(L.mhmr_vit_forward(C.byref(ws["vit_desc"]), x.data_ptr(), ws["feat32"].data_ptr(), ws["ctx16"].data_ptr(),
+                                      P["Kc"], stream), "mhmr_vit_forward")
+        return ws["feat32"].view(x.shape[0], P["N"], P["C"])
+
+    def _prepare(self, x):
+        if not x.is_cuda:
+            raise _lib.MhmrError("multi_hmr_amd.Model.forward runs only on an MI355X (HIP) tensor; there is no CPU fallback")
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != self.img_size or x.shape[3] != self.img_size:
+            raise ValueError(f"x must be [B,3,{self.img_size},{self.img_size}]")
+        P = self._packed
+        if P is None or P["device"] != x.device:
+            P = self._pack(x.device)
+        ws = self._workspace(P, x.shape[0])
+        return P, ws, torch.cuda.current_stream(x.device).cuda_stream
+
+    @torch.no_grad()
+    def forward(self, x, idx=None, det_thresh=0.3, nms_kernel_size=3, K=None, is_training=False, *args, **kwargs):
+        """Same contract as the reference ``Model.forward`` (model.py:205-349): inference -> list of per-person dicts
+        (empty list if nobody is detected); ``is_training=True`` (needs ``idx``) -> dict of batched tensors."""
+        with torch.autocast("cuda", enabled=False):     # demo.forward_model wraps us in fp16 autocast (demo.py:117)
+            return self._forward(x.float().contiguous(), idx, det_thresh, nms_kernel_size, K, is_training)
+
+    def _forward(self, x, idx, det_thresh, nms_kernel_size, K, is_training):
+        L = _lib.lib()
+        P, ws, stream = self._prepare(x)
+        dev, B, G, N, Cdim, Kc = x.device, x.shape[0], P["G"], P["N"], P["C"], P["Kc"]
+        dt = P["dt_id"]
+        K = K.to(device=dev, dtype=torch.float32).contiguous()
+        assert K.shape == (B, 3, 3)
+        Mp = ws["ctx16"].shape[0]
+
+        # 1. backbone (model.py:229) -> feat32 + 16-bit context operand
+        _lib.check(L.mhmr_vit_forward(C.byref(ws["vit_desc"]), x.data_ptr(), ws["feat32"].data_ptr(), ws["ctx16"].data_ptr(), Kc, stream),
+                   "mhmr_vit_forward")
+        # 2. camera embedding (model.py:262) -> zK + context operand columns C..C+98
+        _lib.check(L.mhmr_camera_embed(K.data_ptr(), P["freq"].data_ptr(), B, G, PATCH, ws["zK"].data_ptr(), ws["ctx16"].data_ptr(), Kc,
+                                       Cdim, dt, stream), "mhmr_camera_embed")
+        # 3. detection scores (model.py:135): mlp_classif.0 + ReLU on MFMA, then the C->1 read-out + clamped sigmoid
+        _lib.check(L.mhmr_gemm16(ws["ctx16"].data_ptr(), Kc, P["cls0_w"].data_ptr(), Cdim, Mp, Cdim, Cdim, P["cls0_b"].data_ptr(), None,
+                                 ws["hid"].data_ptr(), Cdim, None, 0, 128, 1, Mp, _lib.EPI_OP16_RELU, dt, stream), "mhmr_gemm16(classif)")
+        _lib.check(L.mhmr_detect_scores(ws["hid"].data_ptr(), Cdim, P["cls2_w"].data_ptr(), P["cls2_b"].data_ptr(), ws["scores"].data_ptr(),
+                                        B * N, Cdim, dt, stream), "mhmr_detect_scores")
+        scores = ws["scores"].view(B, G, G, 1)
+
+        # 4. NMS + threshold + ordered compaction (model.py:141-149), or the caller's idx (training hook, :150-151)
+        if not is_training:
+            thr = float(det_thresh[0] if isinstance(det_thresh, list) else det_thresh)
+            k = int(nms_kernel_size)
+            _lib.check(L.mhmr_detect_count(ws["scores"].data_ptr(), B, G, k, thr, ws["counts"].data_ptr(), stream), "mhmr_detect_count")
+            counts = ws["counts"].cpu()                       # the one host sync (the reference syncs in torch.where)
+            Pn = int(counts.sum())
+            if Pn == 0:
+                return []
+            base = (torch.cumsum(counts, 0) - counts).to(torch.int32).to(dev)
+            det = torch.empty(3, Pn, dtype=torch.int32, device=dev)
+            scores_det = torch.empty(Pn, dtype=torch.float32, device=dev)
+            _lib.check(L.mhmr_detect_write(ws["scores"].data_ptr(), B, G, k, thr, base.data_ptr(), det[0].data_ptr(), det[1].data_ptr(),
+                                           det[2].data_ptr(), scores_det.data_ptr(), stream), "mhmr_detect_write")
+            idx = (det[0].long(), det[1].long(), det[2].long(), torch.zeros(Pn, dtype=torch.long, device=dev))
+        else:
+            assert idx is not None
+            idx = tuple(i.to(dev) for i in idx)
+            Pn = int(idx[0].shape[0])
+            det = torch.stack([idx[0], idx[1], idx[2]]).to(torch.int32).contiguous()
+            counts = torch.bincount(idx[0].cpu(), minlength=B)
+            scores_det = None
+        out = {"scores": scores.clone() if is_training else scores}
+        if Pn == 0:
+            return out
+
+        # 5. ragged query groups (rebatch / pad_to_max semantics, utils/tensor_manip.py:7-45, without the padding)
+        cl = [int(c) for c in counts.tolist()]
+        gstart, chunks, start = [0], [], 0
+        for b, c in enumerate(cl):
+            if c == 0:
+                continue
+            for q0 in range(0, c, 8):
+                chunks += [b, start + q0, min(8, c - q0)]
+            start += c
+            gstart.append(start)
+        nmax = max(cl)
+        meta = torch.tensor(gstart + chunks, dtype=torch.int32).to(dev)
+        gstart_t, chunks_t = meta[: len(gstart)], meta[len(gstart):]
+
+        # 6. HPH (model.py:258-283, 287-298)
+        h = P["hph"]
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        wsp = dict(zc=f(Pn, Cdim), token=f(Pn, h["Ktok"]), x=f(Pn, h["dim"]), xn=f(Pn, h["dim"]),
+                   t1=f(Pn, max(3 * h["inner"], h["mlp"], Cdim)), t2=f(Pn, h["inner"]), dec=f(Pn, h["Ndec"]),
+                   det_row=torch.empty(Pn, dtype=torch.int32, device=dev))
+        d = _lib.HphDesc()
+        d.dtype, d.C, d.G, d.N, d.Kc = dt, Cdim, G, N, Kc
+        d.dim, d.heads, d.mlp, d.depth, d.nb, d.Ktok, d.Ndec = h["dim"], h["heads"], h["mlp"], h["depth"], h["nb"], h["Ktok"], h["Ndec"]
+        d.patch, d.nearness = PATCH, int(bool(self.nearness))
+        d.fn = float(self.img_size / (2 * np.tan(np.radians(self.fovn) / 2)))
+        for n in ("off1_w", "off1_b", "off2_w", "off2_b", "cq_x", "cq_y", "cv_x", "cv_y", "init_tail", "tok_w", "tok_b", "dec_w", "dec_b"):
+            setattr(d, n, h[n])
+        d.layers = C.cast(h["layers"], C.POINTER(_lib.HphLayer))
+        for n, t in wsp.items():
+            setattr(d, n, t.data_ptr())
+        d.kv = ws["kv"].data_ptr()
+        offset, loc = f(Pn, 2), f(Pn, 2)
+        rotmat, rotvec = f(Pn, 53, 3, 3), f(Pn, 53, 3)
+        shape, expression = f(Pn, h["nb"]), f(Pn, 10)
+        dist_pp, dist = f(Pn, 1), f(Pn, 1)
+        _lib.check(L.mhmr_hph_forward(C.byref(d), ws["feat32"].data_ptr(), ws["zK"].data_ptr(), ws["ctx16"].data_ptr(), det[0].data_ptr(),
+                                      det[1].data_ptr(), det[2].data_ptr(), Pn, gstart_t.data_ptr(), len(gstart) - 1, nmax,
+                                      chunks_t.data_ptr(), len(chunks) // 3, K.data_ptr(), B, offset.data_ptr(), loc.data_ptr(),
+                                      rotmat.data_ptr(), rotvec.data_ptr(), shape.data_ptr(), expression.data_ptr(), dist_pp.data_ptr(),
+                                      dist.data_ptr(), stream), "mhmr_hph_forward")
+
+        # 7. SMPL-X layer (model.py:319-321)
+        lb = P["lbs"]
+        V = lb["V"]
+        v3d, v2d = f(Pn, V, 3), f(Pn, V, 2)
+        j3d, j2d, transl = f(Pn, 127, 3), f(Pn, 127, 2), f(Pn, 3)
+        ws_F, ws_A, ws_xf = f(roundup(Pn, 16), lb["Kb"]), f(Pn, 55, 12), f(Pn, 24)
+        _lib.check(L.mhmr_lbs_forward(C.byref(P["lbs_struct"]), rotvec.data_ptr(), shape.data_ptr(), expression.data_ptr(), loc.data_ptr(),
+                                      dist.data_ptr(), K.data_ptr(), det[0].data_ptr(), Pn, ws_F.data_ptr(), ws_A.data_ptr(),
+                                      ws_xf.data_ptr(), v3d.data_ptr(), v2d.data_ptr(), j3d.data_ptr(), j2d.data_ptr(), transl.data_ptr(),
+                                      stream), "mhmr_lbs_forward")
+        out.update({"offset": offset, "dist": dist, "dist_postprocessed": dist_pp, "expression": expression, "rotmat": rotmat,
+                    "shape": shape, "rotvec": rotvec, "loc": loc, "v3d": v3d, "j3d": j3d, "j2d": j2d, "v2d": v2d,
+                    "transl": transl, "transl_pelvis": j3d[:, [0]]})
+        if is_training:
+            return out
+        # 8. per-person dicts (model.py:329-347); v2d / rotmat are computed but not exposed, as in the reference
+        return [{"scores": scores_det[i], "loc": loc[i], "transl": transl[i], "transl_pelvis": out["transl_pelvis"][i],
+                 "rotvec": rotvec[i], "expression": expression[i], "shape": shape[i], "v3d": v3d[i], "j3d": j3d[i], "j2d": j2d[i]}
+                for i in range(Pn)]
+
+
+def C_cast_blocks(arr):
+    return C.cast(arr, C.POINTER(_lib.VitBlock))

@@ -1,0 +1,113 @@
+"""Load-time repacking of reference-format weights / SMPL-X arrays into the layouts the HIP kernels read.
+
+Host-side, run once per (device, precision); nothing here is on the per-image path.
+"""
+from __future__ import annotations
+
+import math
+import numpy as np
+import torch
+
+from . import _lib
+
+OP_DTYPES = {"bf16": (_lib.DT_BF16, torch.bfloat16), "f16": (_lib.DT_F16, torch.float16), "fp16": (_lib.DT_F16, torch.float16)}
+
+
+def roundup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# ---------------------------------------------------------------------------------------------- pos-embed
+def _cubic_weights(t: np.ndarray, A: float = -0.75) -> np.ndarray:
+    """Keys cubic-convolution coefficients for taps at floor-1, floor, floor+1, floor+2."""
+    def inner(x):   # |x| <= 1
+        return ((A + 2) * x - (A + 3)) * x * x + 1
+    def outer(x):   # 1 < |x| < 2
+        return ((A * x - 5 * A) * x + 8 * A) * x - 4 * A
+    return np.stack([outer(t + 1), inner(t), inner(1 - t), outer(2 - t)], axis=-1)
+
+
+def interpolate_pos_embed(pos_embed: np.ndarray, G: int, offset: float = 0.1) -> np.ndarray:
+    """DINOv2 ``interpolate_pos_encoding`` for a G x G grid: the M x M patch table is
+    resampled bicubically (A=-0.75, align_corners=False, no antialias) with the source coordinate computed from
+    the *given* scale factor (G+offset)/M -- not from G/M.  pos_embed: [1, 1+M*M, C] -> [1+G*G, C] (fp32)."""
+    pe = np.asarray(pos_embed, dtype=np.float64)[0]
+    n = pe.shape[0] - 1
+    M = int(round(math.sqrt(n)))
+    assert M * M == n
+    if G == M:
+        return pe.astype(np.float32)
+    C = pe.shape[1]
+    grid = pe[1:].reshape(M, M, C)
+    scale = np.float32(float(G + offset) / M)          # torch keeps the scale as a C++ double made from a python float
+    inv = 1.0 / float(G + offset) * M                  # 1 / scale_factor
+    o = np.arange(G, dtype=np.float64)
+    src = (o + 0.5) * inv - 0.5
+    fl = np.floor(src)
+    t = src - fl
+    w = _cubic_weights(t)                               # [G,4]
+    idx = np.clip(fl[:, None].astype(np.int64) + np.arange(-1, 3)[None, :], 0, M - 1)   # [G,4]
+    rows = np.einsum("ya,yaxc->yxc", w, grid[idx])      # interpolate along y: [G, M, C]
+    out = np.einsum("xa,yxac->yxc", w, rows[:, idx])    # then along x: [G, G, C]
+    return np.concatenate([pe[:1], out.reshape(G * G, C)], axis=0).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------- SMPL-X
+def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) -> dict:
+    """SMPL-X arrays (keys of SMPLX_NEUTRAL.npz) -> mhmr_lbs_consts tensors.
+
+    * basis rows = [posedirs (486) | shapedirs[:, :, :nb] | shapedirs[:, :, 300:310] | v_template | 0-pad],
+      stored [Kb/4][3][Vp][4] so that one float4 per lane feeds four k-steps of the fp32 MFMA;
+    * the dense joint regressor is pre-contracted with the template and the blend shapes (J = J0 + JS.coef);
+    * skinning weights become a K-sparse (index, weight) list, K = max non-zeros per vertex.
+    """
+    from .synthetic import SMPLX_EXTRA_JOINT_VERTS
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    v_t = f64(data["v_template"])
+    V = v_t.shape[0]
+    sd = np.asarray(data["shapedirs"])
+    shp = np.concatenate([f64(sd[:, :, :num_betas]), f64(sd[:, :, 300:310])], axis=-1)       # [V,3,nb+10]
+    pd = f64(data["posedirs"])                                                                # [V,3,486]
+    assert pd.shape[-1] == 486
+    ncoef = num_betas + 10
+    Kb = roundup(486 + ncoef + 1, 16)
+    Vp = roundup(V, 64)
+    D = np.zeros((Kb, 3, Vp), dtype=np.float32)
+    D[:486, :, :V] = pd.transpose(2, 1, 0)
+    D[486:486 + ncoef, :, :V] = shp.transpose(2, 1, 0)
+    D[486 + ncoef, :, :V] = v_t.T
+    basis4 = np.ascontiguousarray(D.reshape(Kb // 4, 4, 3, Vp).transpose(0, 2, 3, 1))         # [Kb/4,3,Vp,4]
+
+    Jr = f64(data["J_regressor"])
+    J0 = Jr @ v_t                                                                             # [55,3]
+    JS = np.einsum("jv,vkl->jkl", Jr, shp)                                                    # [55,3,ncoef]
+
+    W = f64(data["weights"])
+    nnz = (W != 0).sum(axis=1)
+    Kinf = max(1, int(nnz.max()))
+    order = np.argsort(-np.abs(W), axis=1, kind="stable")[:, :Kinf]
+    skin_idx = order.astype(np.int32)
+    skin_w = np.take_along_axis(W, order, axis=1).astype(np.float32)
+
+    parents = np.asarray(data["kintree_table"])[0].astype(np.int64).copy()
+    parents[0] = -1
+    faces = np.asarray(data["f"], dtype=np.int64)
+    lmk_vidx = faces[np.asarray(data["lmk_faces_idx"], dtype=np.int64)].astype(np.int32)       # [51,3]
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dt)
+    return {
+        "V": V, "Vp": Vp, "Kb": Kb, "nb": num_betas, "Kinf": Kinf, "center_joint": person_center_idx,
+        "basis4": t(basis4, torch.float32), "J0": t(J0, torch.float32), "JS": t(JS.reshape(55 * 3, ncoef), torch.float32),
+        "parents": t(parents.astype(np.int32), torch.int32), "skin_idx": t(skin_idx, torch.int32), "skin_w": t(skin_w, torch.float32),
+        "extra_vid": t(np.asarray(SMPLX_EXTRA_JOINT_VERTS, dtype=np.int32), torch.int32), "lmk_vidx": t(lmk_vidx, torch.int32),
+        "lmk_bary": t(np.asarray(data["lmk_bary_coords"], dtype=np.float32), torch.float32),
+        "faces": faces,
+    }
+
+
+def lbs_consts_struct(p: dict) -> "_lib.LbsConsts":
+    c = _lib.LbsConsts()
+    for k in ("V", "Vp", "Kb", "nb", "Kinf", "center_joint"):
+        setattr(c, k, int(p[k]))
+    for k in ("basis4", "J0", "JS", "parents", "skin_idx", "skin_w", "extra_vid", "lmk_vidx", "lmk_bary"):
+        setattr(c, k, p[k].data_ptr())
+    return c

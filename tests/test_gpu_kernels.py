@@ -1,0 +1,247 @@
+"""-m gpu: every HIP kernel family, called through the C ABI, against a plain PyTorch fp32/fp64 reference of the
+same op on the same seeded inputs.  Tolerances: 16-bit-operand kernels are compared on identical (already
+rounded) operands, so only fp32-accumulation-order and output rounding differ; fp32 kernels to ~1e-5."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from multi_hmr_amd import _lib, packing, synthetic  # noqa: E402
+
+DTYPES = [("f16", _lib.DT_F16, torch.float16, 2e-3), ("bf16", _lib.DT_BF16, torch.bfloat16, 1.6e-2)]
+
+
+@pytest.fixture(scope="module")
+def L():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _lib.lib()
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def maxrel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def swap23(t):
+    return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)
+
+
+# ------------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (384, 128, 640)])
+def test_gemm_epilogues(L, name, dt, tdt, tol, M, N, K):
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(dev()).to(tdt)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev()).to(tdt)
+    bias = torch.randn(N, generator=g).to(dev())
+    gamma = torch.randn(N, generator=g).to(dev())
+    ref = A.float() @ W.float().T + bias
+    call = lambda out, ldo, epi, **kw: _lib.check(L.mhmr_gemm16(A.data_ptr(), K, W.data_ptr(), K, M, N, K, bias.data_ptr(),
+                                                                kw.get("gamma"), out.data_ptr(), ldo, kw.get("pos"), kw.get("Np", 0),
+                                                                kw.get("Tp", 128), kw.get("H", 1), kw.get("Mvalid", M), epi, dt, stream()), "gemm")
+    out = torch.zeros(M, N, dtype=tdt, device=dev())
+    call(out, N, _lib.EPI_OP16)
+    assert maxrel(out.float(), ref) < tol, ("op16", maxrel(out.float(), ref))
+    call(out, N, _lib.EPI_OP16_GELU)
+    assert maxrel(out.float(), torch.nn.functional.gelu(ref)) < tol
+    call(out, N, _lib.EPI_OP16_RELU)
+    assert maxrel(out.float(), torch.relu(ref)) < tol
+    o32 = torch.zeros(M, N, device=dev())
+    call(o32, N, _lib.EPI_F32)
+    assert maxrel(o32, ref) < 2e-5, ("f32", maxrel(o32, ref))
+    res = torch.randn(M, N, generator=g).to(dev())
+    o32 = res.clone()
+    call(o32, N, _lib.EPI_RESID, gamma=gamma.data_ptr())
+    assert maxrel(o32, res + gamma * ref) < 2e-5
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+def test_gemm_patch_and_vt_layouts(L, name, dt, tdt, tol):
+    g = torch.Generator(device="cpu").manual_seed(7)
+    # patch epilogue: rows scattered to (b*Tp + 1 + n), + pos[1+n]; rows >= Mvalid dropped
+    B, Np, Tp, N, K = 3, 100, 128, 128, 128
+    M, Mvalid = 384, B * Np
+    A = torch.randn(M, K, generator=g).to(dev()).to(tdt)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev()).to(tdt)
+    bias = torch.randn(N, generator=g).to(dev())
+    pos = torch.randn(1 + Np, N, generator=g).to(dev())
+    out = torch.full((B * Tp, N), 7.0, device=dev())
+    _lib.check(L.mhmr_gemm16(A.data_ptr(), K, W.data_ptr(), K, M, N, K, bias.data_ptr(), None, out.data_ptr(), N, pos.data_ptr(), Np, Tp,
+                             2, Mvalid, _lib.EPI_PATCH, dt, stream()), "gemm patch")
+    ref = (A.float() @ W.float().T + bias)[:Mvalid].view(B, Np, N) + pos[1:]
+    got = out.view(B, Tp, N)
+    assert maxrel(got[:, 1:1 + Np], ref) < 2e-5
+    assert torch.all(got[:, 0] == 7.0) and torch.all(got[:, 1 + Np:] == 7.0)       # untouched rows
+    # V^T epilogue
+    B, H, Tp = 2, 2, 256
+    M, N, K = B * Tp, H * 64, 64
+    A = torch.randn(M, K, generator=g).to(dev()).to(tdt)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev()).to(tdt)
+    bias = torch.randn(N, generator=g).to(dev())
+    vt = torch.zeros(B, H, 64, Tp, dtype=tdt, device=dev())
+    _lib.check(L.mhmr_gemm16(A.data_ptr(), K, W.data_ptr(), K, M, N, K, bias.data_ptr(), None, vt.data_ptr(), 0, None, 0, Tp, H, M,
+                             _lib.EPI_VT, dt, stream()), "gemm vt")
+    ref = (A.float() @ W.float().T + bias).view(B, Tp, H, 64).permute(0, 2, 3, 1)        # [B,H,64,t]
+    perm = swap23(torch.arange(Tp, device=dev()))
+    assert maxrel(vt.float()[..., perm], ref) < tol
+
+
+# ------------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("B,H,T", [(2, 3, 200), (1, 2, 256), (1, 1, 65), (2, 6, 257)])
+def test_attention(L, name, dt, tdt, tol, B, H, T):
+    C, Tp = H * 64, packing.roundup(T, 128)
+    g = torch.Generator(device="cpu").manual_seed(T)
+    q = torch.randn(B, Tp, H, 64, generator=g).to(dev()).to(tdt)
+    k = torch.randn(B, Tp, H, 64, generator=g).to(dev()).to(tdt)
+    v = torch.randn(B, Tp, H, 64, generator=g).to(dev()).to(tdt)
+    k[0, min(T - 1, 70), 0] *= 6.0          # a spiked key forces the running-max rescale branch late in the loop
+    qk = torch.cat([q.reshape(B * Tp, C), k.reshape(B * Tp, C)], dim=1).contiguous()
+    vt = torch.zeros(B, H, 64, Tp, dtype=tdt, device=dev())
+    vt[..., swap23(torch.arange(Tp, device=dev()))] = v.permute(0, 2, 3, 1)
+    out = torch.zeros(B * Tp, C, dtype=tdt, device=dev())
+    _lib.check(L.mhmr_attention16(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), B, T, Tp, C, H, dt, stream()), "attention")
+    qf, kf, vf = [t.double().permute(0, 2, 1, 3) for t in (q, k, v)]
+    att = torch.softmax(qf[:, :, :T] @ kf[:, :, :T].transpose(-1, -2) * 0.125, dim=-1) @ vf[:, :, :T]
+    ref = att.permute(0, 2, 1, 3).reshape(B, T, C)
+    got = out.view(B, Tp, C)[:, :T].double()
+    err = float((got - ref).abs().max())
+    assert err < (4e-3 if name == "f16" else 3e-2), err
+    assert torch.isfinite(out.float()).all()
+
+
+# ------------------------------------------------------------------------------------------------------ norms, patchify
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("C", [384, 768, 1024])
+def test_layernorm16(L, name, dt, tdt, tol, C):
+    x = torch.randn(301, C, device=dev()) * 3 + 1
+    w, b = torch.randn(C, device=dev()), torch.randn(C, device=dev())
+    out = torch.zeros(301, C, dtype=tdt, device=dev())
+    _lib.check(L.mhmr_layernorm16(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), 301, C, 1e-6, dt, stream()), "ln")
+    ref = torch.nn.functional.layer_norm(x, (C,), w, b, 1e-6)
+    assert maxrel(out.float(), ref) < tol
+
+
+def test_linear_f32_and_layernorm_f32(L):
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for (M, N, K, act) in [(37, 130, 48, 0), (5, 2, 384, 1), (64, 1024, 1456, 2), (257, 341, 1024, 0)]:
+        X = torch.randn(M, K, generator=g).to(dev())
+        W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev())
+        b = torch.randn(N, generator=g).to(dev())
+        R = torch.randn(M, N, generator=g).to(dev())
+        Y = R.clone()
+        _lib.check(L.mhmr_linear_f32(X.data_ptr(), K, None, W.data_ptr(), K, b.data_ptr(), Y.data_ptr(), N, Y.data_ptr(), N, M, N, K, act,
+                                     stream()), "linear")
+        ref = X.double() @ W.double().T + b.double()
+        ref = torch.relu(ref) if act == 1 else torch.nn.functional.gelu(ref) if act == 2 else ref
+        assert maxrel(Y, ref + R.double()) < 1e-5, (M, N, K, act)
+    # gathered rows
+    X = torch.randn(50, 64, device=dev())
+    W = torch.randn(20, 64, device=dev())
+    ridx = torch.tensor([3, 3, 49, 0, 17], dtype=torch.int32, device=dev())
+    Y = torch.zeros(5, 20, device=dev())
+    _lib.check(L.mhmr_linear_f32(X.data_ptr(), 64, ridx.data_ptr(), W.data_ptr(), 64, None, None, 0, Y.data_ptr(), 20, 5, 20, 64, 0, stream()), "linear")
+    assert maxrel(Y, X[ridx.long()].double() @ W.double().T) < 1e-5
+    x = torch.randn(33, 1024, device=dev()) * 2 - 0.5
+    w, b = torch.randn(1024, device=dev()), torch.randn(1024, device=dev())
+    out = torch.zeros_like(x)
+    _lib.check(L.mhmr_layernorm_f32(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), 33, 1024, 1e-5, stream()), "ln32")
+    assert maxrel(out, torch.nn.functional.layer_norm(x.double(), (1024,), w.double(), b.double(), 1e-5)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------ detection
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5])
+def test_nms_threshold_compaction(L, k):
+    from oracle.multihmr_ref import nms
+    B, G = 3, 16
+    g = torch.Generator(device="cpu").manual_seed(k)
+    s = torch.rand(B, G * G, generator=g)
+    s[0, 5] = s[0, 6] = 0.93          # an exact tie between neighbours: both survive (hmax == heat)
+    s[2] *= 0.1                         # an image without detections
+    thr = 0.8
+    sc = s.to(dev()).contiguous()
+    counts = torch.zeros(B, dtype=torch.int32, device=dev())
+    _lib.check(L.mhmr_detect_count(sc.data_ptr(), B, G, k, thr, counts.data_ptr(), stream()), "count")
+    heat = s.view(B, 1, G, G)
+    heat = nms(heat, k) if k > 1 else heat
+    ref_idx = torch.where(heat.permute(0, 2, 3, 1) >= thr)
+    ref_counts = torch.bincount(ref_idx[0], minlength=B)
+    assert counts.cpu().tolist() == ref_counts.tolist()
+    P = int(ref_counts.sum())
+    base = (torch.cumsum(counts, 0) - counts).to(torch.int32)
+    det = torch.zeros(3, P, dtype=torch.int32, device=dev())
+    dsc = torch.zeros(P, device=dev())
+    _lib.check(L.mhmr_detect_write(sc.data_ptr(), B, G, k, thr, base.data_ptr(), det[0].data_ptr(), det[1].data_ptr(), det[2].data_ptr(),
+                                   dsc.data_ptr(), stream()), "write")
+    assert det.cpu().long().tolist() == [ref_idx[0].tolist(), ref_idx[1].tolist(), ref_idx[2].tolist()]
+    assert torch.equal(dsc.cpu(), heat[ref_idx[0], ref_idx[3], ref_idx[1], ref_idx[2]])
+
+
+def test_camera_embed(L):
+    from oracle.multihmr_ref import embedd_camera
+    B, G, C, Kc = 2, 16, 384, 512
+    K = synthetic.get_camera_K(G * 14, B)
+    K[1, 0, 0] *= 1.1
+    K[1, 0, 2] += 5
+    K[1, 0, 1] = 0.3       # a skewed camera exercises the general 3x3 inverse
+    freq = torch.stack([torch.linspace(1.0, 32.0, 16) for _ in range(3)]).to(dev()).contiguous()
+    zK = torch.zeros(B * G * G, 99, device=dev())
+    ctx = torch.full((B * G * G, Kc), 5.0, dtype=torch.float16, device=dev())
+    Kd = K.to(dev()).contiguous()
+    _lib.check(L.mhmr_camera_embed(Kd.data_ptr(), freq.data_ptr(), B, G, 14, zK.data_ptr(), ctx.data_ptr(), Kc, C, _lib.DT_F16, stream()), "cam")
+    ref = embedd_camera(K, G).reshape(B * G * G, 99)
+    assert float((zK.cpu() - ref).abs().max()) < 2e-4     # sin/cos of arguments up to ~60 rad in fp32
+    assert torch.all(ctx[:, :C] == 5.0) and torch.all(ctx[:, C + 99:] == 0.0)
+    assert float((ctx[:, C:C + 99].float().cpu() - ref).abs().max()) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------------ LBS
+@pytest.mark.parametrize("P", [1, 5, 70])
+def test_lbs_against_oracle(L, smplx_data, P):
+    import ctypes as C
+    from oracle import smplx_ref
+    from oracle.multihmr_ref import smpl_layer_forward
+    pk = packing.pack_smplx(smplx_data, 10, dev())
+    cs = packing.lbs_consts_struct(pk)
+    g = torch.Generator(device="cpu").manual_seed(P)
+    pose = 0.35 * torch.randn(P, 53, 3, generator=g)
+    pose[0, 3] = 0                                            # a zero rotation vector
+    shape, expr = torch.randn(P, 10, generator=g), torch.randn(P, 10, generator=g)
+    B = 3
+    det_b = torch.randint(0, B, (P,), generator=g).sort().values
+    K = synthetic.get_camera_K(448, B)
+    K[:, 0, 2] += torch.arange(B) * 4.0
+    loc = 448 * torch.rand(P, 2, generator=g)
+    dist = 2 + 6 * torch.rand(P, 1, generator=g)
+    ref = smpl_layer_forward(smplx_ref.SMPLX(smplx_data, num_betas=10), pose, shape, loc, dist, K[det_b], expr)
+    d = lambda t, dt=torch.float32: t.to(device=dev(), dtype=dt).contiguous()
+    V = pk["V"]
+    f = lambda *s: torch.zeros(*s, device=dev())
+    v3d, v2d, j3d, j2d, transl = f(P, V, 3), f(P, V, 2), f(P, 127, 3), f(P, 127, 2), f(P, 3)
+    wsF, wsA, wsX = f(packing.roundup(P, 16), pk["Kb"]), f(P, 55, 12), f(P, 24)
+    args = [d(pose), d(shape), d(expr), d(loc), d(dist), d(K), d(det_b, torch.int32)]
+    _lib.check(L.mhmr_lbs_forward(C.byref(cs), *[a.data_ptr() for a in args], P, wsF.data_ptr(), wsA.data_ptr(), wsX.data_ptr(),
+                                  v3d.data_ptr(), v2d.data_ptr(), j3d.data_ptr(), j2d.data_ptr(), transl.data_ptr(), stream()), "lbs")
+    for name, got in (("v3d", v3d), ("j3d", j3d), ("transl", transl)):
+        err = float((got.cpu() - ref[name]).abs().max())
+        assert err < 2e-5, (name, err)                        # metres
+    for name, got in (("v2d", v2d), ("j2d", j2d)):
+        err = float((got.cpu() - ref[name]).abs().max())
+        assert err < 5e-3, (name, err)                        # pixels
+    assert float((j3d[:, [0]].cpu() - ref["transl_pelvis"]).abs().max()) < 2e-5

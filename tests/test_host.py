@@ -1,0 +1,88 @@
+"""-m "not gpu": host-side logic of the product -- the C-ABI library loads and exports every declared symbol, the
+load-time repacking is exact, the nn.Module surface matches the reference's, and nothing computes on the CPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from multi_hmr_amd import Model, _lib, packing, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    _lib.build()
+    lib = _lib.lib()
+    assert lib.mhmr_version() == 100
+    header = open(os.path.join(ROOT, "include", "mhmr.h")).read()
+    declared = set(re.findall(r"\bint\s+(mhmr_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    # argument validation happens before any launch, so it is testable without a GPU
+    assert lib.mhmr_prof_enable(99) == -1
+
+
+def test_pos_embed_bicubic_matches_torch_scale_factor_form():
+    from oracle.dinov2_ref import interpolate_pos_embed
+    g = torch.Generator().manual_seed(0)
+    pe = torch.randn(1, 1 + 37 * 37, 48, generator=g) * 0.02
+    for G in (16, 32, 48, 64, 92, 37):
+        ref = interpolate_pos_embed(pe, G)[0].numpy()
+        got = packing.interpolate_pos_embed(pe.numpy(), G)
+        assert got.shape == (1 + G * G, 48)
+        assert np.abs(got - ref).max() < 1e-6, G      # torch evaluates the source coordinate in fp32
+
+
+def test_pack_smplx_is_an_exact_refactoring_of_smplx_lbs(smplx_data):
+    """J0 + JS.coef == J_regressor.(v_template + blendshapes) and F.D == v_template + shape blend + pose blend."""
+    from oracle import smplx_ref
+    pk = packing.pack_smplx(smplx_data, 10, "cpu")
+    bm = smplx_ref.SMPLX(smplx_data, num_betas=10)
+    g = torch.Generator().manual_seed(0)
+    coef = torch.randn(20, generator=g)
+    v_shaped = bm.v_template + torch.einsum("l,mkl->mk", coef, torch.cat([bm.shapedirs, bm.expr_dirs], -1))
+    J = bm.J_regressor @ v_shaped
+    J2 = pk["J0"] + (pk["JS"] @ coef).reshape(55, 3)
+    assert float((J - J2).abs().max()) < 2e-6
+    pf = 0.1 * torch.randn(486, generator=g)
+    F = torch.zeros(pk["Kb"])
+    F[:486], F[486:506], F[506] = pf, coef, 1.0
+    D = pk["basis4"].permute(0, 3, 1, 2).reshape(pk["Kb"], 3, pk["Vp"])          # [k, axis, v]
+    v_posed = torch.einsum("k,kav->va", F, D)[: pk["V"]]
+    ref = v_shaped + (pf @ bm.posedirs).view(-1, 3)
+    assert float((v_posed - ref).abs().max()) < 2e-6
+    assert pk["Kinf"] == 4 and pk["Vp"] % 64 == 0 and pk["Kb"] % 16 == 0
+    W = torch.zeros(pk["V"], 55).scatter_add_(1, pk["skin_idx"].long(), pk["skin_w"])
+    assert torch.allclose(W, bm.lbs_weights, atol=0)
+    assert (pk["lmk_vidx"].numpy() == bm.faces[bm.lmk_faces_idx.numpy()]).all()
+
+
+def test_model_surface_matches_reference(smplx_data, mean_params):
+    m = Model(backbone="dinov2_vits14", img_size=448, smplx_data=smplx_data, mean_params=mean_params, backbone_depth=2,
+              some_training_flag=123, train_return_type="foo")          # arbitrary extra kwargs are swallowed (model.py:48-49)
+    sd = synthetic.make_state_dict("dinov2_vits14", 448, depth_override=2, mean_params=mean_params)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    assert m.load_state_dict(sd, strict=False).missing_keys == []
+    assert m.img_size == 448 and m.patch_size == 14 and m.nearness is True and m.embed_dim == 384
+    assert m.smpl_layer["neutral_10"].bm_x.faces.shape == (20908, 3)            # demo.py:310
+    assert m.smpl_layer["neutral_10"].person_center_idx == 15
+    assert m.x_attention_head.init_body_pose.shape == (1, 318)
+    # Appendix C shapes (ViT-S: Cc = 483, token_dim = 814)
+    assert m.state_dict()["x_attention_head.transformer.to_token_embedding.weight"].shape == (1024, 814)
+    assert m.state_dict()["x_attention_head.cross_queries_x"].shape == (32, 483)
+    assert m.state_dict()["x_attention_head.transformer.transformer.layers.1.1.fn.to_kv.weight"].shape == (512, 483)
+
+
+def test_no_cpu_fallback(smplx_data, mean_params):
+    m = Model(backbone="dinov2_vits14", img_size=224, smplx_data=smplx_data, mean_params=mean_params, backbone_depth=1)
+    with pytest.raises(_lib.MhmrError):
+        m(torch.zeros(1, 3, 224, 224), K=synthetic.get_camera_K(224))
+    # the product never imports the oracle
+    for f in os.listdir(os.path.join(ROOT, "multi_hmr_amd")):
+        if f.endswith(".py"):
+            assert "oracle" not in open(os.path.join(ROOT, "multi_hmr_amd", f)).read().replace("the oracle", "").replace("CPU oracle", ""), f
