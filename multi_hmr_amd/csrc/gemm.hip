@@ -95,53 +95,83 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     }
 
     // ---- epilogue ----
+    // Row-major outputs go through LDS so that global accesses are whole contiguous row segments (a direct store
+    // from the MFMA layout touches 32 rows x 8..16 B per instruction at a power-of-two row stride, which camps on
+    // one memory channel).  Each wave transposes its own 64(m) x 64(n) sub-tile in a private 16 KiB LDS region:
+    // write in fragment order with an XOR swizzle, read back row-contiguous (16 B per lane).
     if constexpr (ROWMAJOR) {
+        __syncthreads();  // every wave is done reading the last K tile
+        char* wl = smem + w * 16384;
+        const int mb = m0 + 64 * wq_, nb = n0 + 64 * wp_;
+        constexpr bool OUT16 = (EPI == EPI_OP16 || EPI == EPI_OP16_GELU || EPI == EPI_OP16_RELU);
+        if constexpr (OUT16) {
+            // bias + activation + convert here (lane owns 4 consecutive n), LDS rows = 64 n x 2 B = 128 B
 #pragma unroll
-        for (int qj = 0; qj < 2; ++qj) {
-            const int m = m0 + 64 * wq_ + 32 * qj + l31;
-            size_t orow = (size_t)m;
-            const float* posrow = nullptr;
-            if constexpr (EPI == EPI_PATCH) {
-                const int b = m / g.Np, n_in = m - b * g.Np;
-                orow = (size_t)b * g.Tp + 1 + n_in;
-                posrow = g.pos + (size_t)(1 + n_in) * g.N;
-            }
-            if constexpr (EPI == EPI_PATCH) {
-                if (m >= g.Mvalid) continue;
-            }
-#pragma unroll
-            for (int pi = 0; pi < 2; ++pi) {
+            for (int pi = 0; pi < 2; ++pi)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-                    const int n = n0 + 64 * wp_ + 32 * pi + 8 * rg + 4 * hi;
-                    f32x4 v;
+                    const int nl = 32 * pi + 8 * rg + 4 * hi;
+                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                    if (g.bias) bv = *(const f32x4*)(g.bias + nb + nl);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[pi][qj][4 * rg + e];
-                    if (g.bias) v += *(const f32x4*)(g.bias + n);
-                    if constexpr (EPI == EPI_OP16 || EPI == EPI_OP16_GELU || EPI == EPI_OP16_RELU) {
-                        if constexpr (EPI == EPI_OP16_GELU) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                        }
-                        if constexpr (EPI == EPI_OP16_RELU) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                        }
+                    for (int qj = 0; qj < 2; ++qj) {
+                        const int ml = 32 * qj + l31;
                         V4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
-                        *(V4*)((T*)g.out + orow * g.ldo + n) = o;
-                    } else if constexpr (EPI == EPI_RESID) {
-                        float* op = (float*)g.out + orow * g.ldo + n;
-                        const f32x4 r = *(const f32x4*)op;
-                        const f32x4 gm = *(const f32x4*)(g.gamma + n);
-                        *(f32x4*)op = r + gm * v;
-                    } else if constexpr (EPI == EPI_PATCH) {
-                        v += *(const f32x4*)(posrow + n);
-                        *(f32x4*)((float*)g.out + orow * g.ldo + n) = v;
-                    } else {  // EPI_F32
-                        *(f32x4*)((float*)g.out + orow * g.ldo + n) = v;
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[pi][qj][4 * rg + e] + bv[e];
+                            if constexpr (EPI == EPI_OP16_GELU) v = gelu_fast(v);
+                            if constexpr (EPI == EPI_OP16_RELU) v = fmaxf(v, 0.f);
+                            o[e] = (T)v;
+                        }
+                        *(V4*)(wl + ml * 128 + (((nl >> 2) ^ ((ml & 7) << 1)) * 8)) = o;
                     }
+                }
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): wave-private region, no barrier needed
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = 8 * it + (lane >> 3), c16 = lane & 7;
+                const u32x4 v = *(const u32x4*)(wl + row * 128 + ((c16 ^ (row & 7)) * 16));
+                *(u32x4*)((T*)g.out + (size_t)(mb + row) * g.ldo + nb + c16 * 8) = v;
+            }
+        } else {
+            // fp32 tile: LDS rows = 64 n x 4 B = 256 B
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int ch = 8 * pi + 2 * rg + hi;  // 16-byte chunk = (n_local / 4)
+#pragma unroll
+                    for (int qj = 0; qj < 2; ++qj) {
+                        const int ml = 32 * qj + l31;
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[pi][qj][4 * rg + e];
+                        *(f32x4*)(wl + ml * 256 + ((ch ^ (ml & 15)) * 16)) = v;
+                    }
+                }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            const int c = lane & 15;
+            const int n = nb + 4 * c;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gm = {1.f, 1.f, 1.f, 1.f};
+            if (g.bias) bv = *(const f32x4*)(g.bias + n);
+            if constexpr (EPI == EPI_RESID) gm = *(const f32x4*)(g.gamma + n);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row = 4 * it + (lane >> 4);
+                f32x4 v = *(const f32x4*)(wl + row * 256 + ((c ^ (row & 15)) * 16)) + bv;
+                const int m = mb + row;
+                if constexpr (EPI == EPI_RESID) {
+                    float* op = (float*)g.out + (size_t)m * g.ldo + n;
+                    *(f32x4*)op = *(const f32x4*)op + gm * v;
+                } else if constexpr (EPI == EPI_PATCH) {
+                    if (m < g.Mvalid) {
+                        const int b = m / g.Np, n_in = m - b * g.Np;
+                        v += *(const f32x4*)(g.pos + (size_t)(1 + n_in) * g.N + n);
+                        *(f32x4*)((float*)g.out + ((size_t)b * g.Tp + 1 + n_in) * g.ldo + n) = v;
+                    }
+                } else {  // EPI_F32
+                    *(f32x4*)((float*)g.out + (size_t)m * g.ldo + n) = v;
                 }
             }
         }
