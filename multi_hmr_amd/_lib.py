@@ -12,7 +12,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmhmr.so")
-SOURCES = ["gemm.hip", "attention.hip", "vit_misc.hip", "hph.hip", "lbs.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "vit_misc.hip", "hph.hip", "lbs.hip", "capi.hip"]
 HEADERS = ["mhmr_common.h", "mhmr_internal.h", os.path.join("..", "..", "include", "mhmr.h")]
 
 DT_BF16, DT_F16 = 0, 1

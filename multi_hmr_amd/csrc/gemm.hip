@@ -12,6 +12,7 @@
 // D's columns (one per lane).  For row-major [m][n] outputs the WEIGHT tile is the first operand so every lane
 // owns 4 consecutive n of one m (8/16-byte stores); for the transposed V^T output the ACTIVATION tile is first
 // so every lane owns 4 consecutive tokens of one channel.
+#include <stdlib.h>
 #include "mhmr_common.h"
 #include "mhmr_internal.h"
 
@@ -233,12 +234,19 @@ int launch_dt(const GemmArgs& g, hipStream_t s) {
 
 }  // namespace
 
+bool mhmr_gemm256_eligible(const GemmArgs& g);
+int mhmr_launch_gemm256(const GemmArgs& g, int dtype, hipStream_t s);
+// MHMR_GEMM128=1 forces the 128x128 kernel everywhere (A/B measurements, bisecting)
+static const bool g_force_gemm128 = getenv("MHMR_GEMM128") != nullptr;
+
 int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % BM || g.N % BN || g.K % BK) return MHMR_ERR_BAD_SHAPE;
     if (g.lda % 8 || g.ldw % 8) return MHMR_ERR_BAD_SHAPE;
     if (g.epi == EPI_VT && (g.Tp % BM || g.N % 64)) return MHMR_ERR_BAD_SHAPE;
     prof_begin(PROF_GEMM, s);
-    const int rc = dtype == MHMR_DT_F16 ? launch_dt<MHMR_DT_F16>(g, s) : launch_dt<MHMR_DT_BF16>(g, s);
+    int rc;
+    if (!g_force_gemm128 && mhmr_gemm256_eligible(g)) rc = mhmr_launch_gemm256(g, dtype, s);
+    else rc = dtype == MHMR_DT_F16 ? launch_dt<MHMR_DT_F16>(g, s) : launch_dt<MHMR_DT_BF16>(g, s);
     prof_end(PROF_GEMM, s, 2.0 * g.M * g.N * g.K);
     return rc;
 }

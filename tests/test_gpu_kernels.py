@@ -44,7 +44,8 @@ def swap23(t):
 
 # ------------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (384, 128, 640)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (384, 128, 640),
+                                   (256, 256, 128), (512, 256, 1024), (256, 768, 384)])   # the last three run the 256x256 8-phase kernel
 def test_gemm_epilogues(L, name, dt, tdt, tol, M, N, K):
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).to(dev()).to(tdt)
@@ -98,6 +99,31 @@ def test_gemm_patch_and_vt_layouts(L, name, dt, tdt, tol):
     _lib.check(L.mhmr_gemm16(A.data_ptr(), K, W.data_ptr(), K, M, N, K, bias.data_ptr(), None, vt.data_ptr(), 0, None, 0, Tp, H, M,
                              _lib.EPI_VT, dt, stream()), "gemm vt")
     ref = (A.float() @ W.float().T + bias).view(B, Tp, H, 64).permute(0, 2, 3, 1)        # [B,H,64,t]
+    perm = swap23(torch.arange(Tp, device=dev()))
+    assert maxrel(vt.float()[..., perm], ref) < tol
+    # same two layouts through the 256x256 kernel (blocks straddle image boundaries: Tp = 384, 3 x 256 rows)
+    B, Np, Tp, N, K = 3, 170, 256, 256, 256
+    M, Mvalid = 512, B * Np
+    A = torch.randn(M, K, generator=g).to(dev()).to(tdt)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev()).to(tdt)
+    bias = torch.randn(N, generator=g).to(dev())
+    pos = torch.randn(1 + Np, N, generator=g).to(dev())
+    out = torch.full((B * Tp, N), 7.0, device=dev())
+    _lib.check(L.mhmr_gemm16(A.data_ptr(), K, W.data_ptr(), K, M, N, K, bias.data_ptr(), None, out.data_ptr(), N, pos.data_ptr(), Np, Tp,
+                             2, Mvalid, _lib.EPI_PATCH, dt, stream()), "gemm patch 256")
+    ref = (A.float() @ W.float().T + bias)[:Mvalid].view(B, Np, N) + pos[1:]
+    got = out.view(B, Tp, N)
+    assert maxrel(got[:, 1:1 + Np], ref) < 2e-5
+    assert torch.all(got[:, 0] == 7.0) and torch.all(got[:, 1 + Np:] == 7.0)
+    B, H, Tp = 2, 4, 384
+    M, N, K = B * Tp, H * 64, 128
+    A = torch.randn(M, K, generator=g).to(dev()).to(tdt)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev()).to(tdt)
+    bias = torch.randn(N, generator=g).to(dev())
+    vt = torch.zeros(B, H, 64, Tp, dtype=tdt, device=dev())
+    _lib.check(L.mhmr_gemm16(A.data_ptr(), K, W.data_ptr(), K, M, N, K, bias.data_ptr(), None, vt.data_ptr(), 0, None, 0, Tp, H, M,
+                             _lib.EPI_VT, dt, stream()), "gemm vt 256")
+    ref = (A.float() @ W.float().T + bias).view(B, Tp, H, 64).permute(0, 2, 3, 1)
     perm = swap23(torch.arange(Tp, device=dev()))
     assert maxrel(vt.float()[..., perm], ref) < tol
 
