@@ -1,23 +1,26 @@
-// 256x256x64 "8-phase ping-pong" GEMM for the large ViT linears (same math and epilogues as gemm.hip).
+// 256x256x64 persistent "8-phase ping-pong" GEMM for the large ViT linears (same math and epilogues as gemm.hip).
 //
-//   workgroup = 8 waves (2 x 4) on one CU (1 block/CU, 2 waves per SIMD), 128 KiB LDS = 2 K-tile buffers (even/odd)
-//   x 4 half-tile slots (P0, P1, Q0, Q1; 128 rows x 64 k, 16 KiB each).  A wave owns 64 P-rows in EACH P half and
-//   32 Q-rows in EACH Q half, so its 128x64 output splits into 4 quadrants and every half-tile slot is read in
-//   exactly one phase by all waves:
+//   workgroup = 8 waves (2 x 4) on one CU (1 block/CU, 2 waves per SIMD); LDS = 128 KiB DMA ring (2 K-tile buffers
+//   even/odd x 4 half-tile slots P0, P1, Q0, Q1; 128 rows x 64 k, 16 KiB each) + 32 KiB epilogue staging.  A wave owns
+//   64 P-rows in EACH P half and 32 Q-rows in EACH Q half, so its 128x64 output splits into 4 quadrants and every
+//   half-tile slot is read in exactly one phase by all waves:
 //
-//     phase   ds_read (slot -> regs)        MFMA (8 x v_mfma_f32_32x32x16)        LDS-DMA issued (2 x glds16 / thread)
+//     phase   ds_read (slot -> regs)        MFMA (16 x v_mfma_f32_16x16x32)       LDS-DMA issued (2 x glds16 / thread)
 //     1 / 5   P0 -> PR (8), Q0 -> QA (4)    acc[0][0] += PR x QA                  Q1(odd,  t1) / Q1(even, t2)
 //     2 / 6   Q1 -> QB (4)                  acc[0][1] += PR x QB                  P1(odd,  t1) / P1(even, t2)
 //     3 / 7   P1 -> PR (8)                  acc[1][1] += PR x QB                  Q0(even, t2) / Q0(odd,  t3)
 //     4 / 8   --                            acc[1][0] += PR x QA                  P0(even, t2) / P0(odd,  t3)
 //
 //   Every phase is  [ds_reads ; DMA issue ; s_waitcnt vmcnt(8)] s_barrier [MFMAs] s_barrier.  The two wave groups
-//   (wp = 0 / 1, one wave of each per SIMD) run ONE barrier apart, so while one group's 8 MFMAs occupy the SIMD's
-//   matrix pipe the other group issues its LDS reads and DMA -- the pipe never waits for a load phase.
-//   vmcnt(8) after each issue = "the half-tile issued 4 phases ago has landed": every slot is waited for one phase
-//   before it is first read (RAW needs the wait + a barrier) and is re-filled >= 2 phases after its last read
-//   (WAR), never draining the DMA queue inside the loop.  Tail iterations re-issue the last K tile into slots that
-//   are no longer read, which keeps the counted waits uniform.
+//   (wp = 0 / 1, one wave of each per SIMD) run ONE barrier apart, so while one group's 16 MFMAs (8 independent
+//   accumulators: no dependent-issue stalls with only one computing wave per SIMD) occupy the SIMD's matrix pipe the
+//   other group issues its LDS reads and DMA.  vmcnt(8) after each issue = "the half-tile issued 4 phases ago has
+//   landed": every slot is waited for one phase before it is first read (RAW = wait + barrier) and re-filled >= 2
+//   phases after its last read (WAR); the DMA queue is never drained inside the K loop.
+//
+//   Persistent: a block walks its output tiles; the K-tile indices t2, t3 that run past the end of one tile are the
+//   first K tiles of the NEXT tile, so the ring stays full across tile boundaries and the next tile's operands stream
+//   in underneath the epilogue (which transposes through its own LDS region and finishes with one vmcnt(0)).
 #include "mhmr_common.h"
 #include "mhmr_internal.h"
 
@@ -26,6 +29,8 @@ namespace {
 constexpr int HT = 16384;           // bytes per half-tile slot (128 rows x 128 B)
 constexpr int BUF = 4 * HT;         // one K-tile buffer: P0 | P1 | Q0 | Q1
 constexpr int SLOT_P0 = 0, SLOT_P1 = HT, SLOT_Q0 = 2 * HT, SLOT_Q1 = 3 * HT;
+constexpr int STAGE_OFF = 2 * BUF;  // 8 waves x 4 KiB epilogue staging
+constexpr int LDS_BYTES = 2 * BUF + 8 * 4096;
 
 template <int DT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
@@ -37,68 +42,67 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = w >> 2, wq = w & 3;
-    const int hi = lane >> 5, l31 = lane & 31;
+    const int g4 = lane >> 4, l15 = lane & 15;   // 16x16x32 fragments: row/col = lane & 15, k-group / row-quad = lane >> 4
 
     constexpr bool ROWMAJOR = (EPI != EPI_VT);
-    const int nbn = g.N / 256;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = bid % nbn, tm = bid / nbn;
-    const int m0 = tm * 256, n0 = tn * 256;
     // P = first MFMA operand (D rows, 4 consecutive per accumulator quad), Q = second (D columns, one per lane)
     const T* Pm = ROWMAJOR ? (const T*)g.W : (const T*)g.A;
     const T* Qm = ROWMAJOR ? (const T*)g.A : (const T*)g.W;
     const int ldp = ROWMAJOR ? g.ldw : g.lda, ldq = ROWMAJOR ? g.lda : g.ldw;
-    const int p0 = ROWMAJOR ? n0 : m0, q0 = ROWMAJOR ? m0 : n0;
+
+    // ---- persistent tile walk: XCD x owns a contiguous run of G/8 tiles in every round (neighbouring tiles share an L2) ----
+    const int nbn = g.N / 256, ntiles = (g.M / 256) * nbn;
+    const int G = gridDim.x, b = blockIdx.x;
+    const int first = (G & 7) == 0 ? (b & 7) * (G >> 3) + (b >> 3) : b;
 
     // ---- DMA source addressing: one half-tile = 2 passes of 64 rows; lane-linear LDS image, swizzle on the source ----
     const int srow = tid >> 3;                                  // 0..63
     const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
-    const T* p_src = Pm + (size_t)(p0 + srow) * ldp + schunk * 8;
-    const T* q_src = Qm + (size_t)(q0 + srow) * ldq + schunk * 8;
     const int nt = g.K / 64;
-
+    auto tile_src = [&](int tix, const T*& ps, const T*& qs, int& p0, int& q0) {
+        const int tn = tix % nbn, tm = tix / nbn;
+        p0 = ROWMAJOR ? tn * 256 : tm * 256;
+        q0 = ROWMAJOR ? tm * 256 : tn * 256;
+        ps = Pm + (size_t)(p0 + srow) * ldp + schunk * 8;
+        qs = Qm + (size_t)(q0 + srow) * ldq + schunk * 8;
+    };
     auto dma = [&](const T* src, int ld, int half, int kt, int lds_off) {
-        kt = kt < nt ? kt : nt - 1;                             // tail: harmless re-load of the last tile
         const T* s = src + (size_t)(128 * half) * ld + kt * 64;
         char* d = smem + lds_off + w * 1024;
         glds16(s, d);
         glds16(s + (size_t)64 * ld, d + 8192);
     };
 
-    // ---- fragment read addressing ----
-    const int fsw = (lane >> 1) & 7;
-    const int pr_off = (64 * wp + l31) * 128, q_off = (32 * wq + l31) * 128;
-    int co[4];
+    // ---- fragment read addressing (16-row sub-tiles; chunk = 4*ks + g4 within the 128-byte row) ----
+    const int fsw = l15 >> 1;
+    const int pr_off = (64 * wp + l15) * 128, q_off = (32 * wq + l15) * 128;
+    int co[2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) co[ks] = ((2 * ks + hi) ^ fsw) * 16;
+    for (int ks = 0; ks < 2; ++ks) co[ks] = ((4 * ks + g4) ^ fsw) * 16;
 
-    f32x16 acc[2][2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][s][r] = 0.f;
-    V8 PR[2][4], QA[4], QB[4];
+    f32x4 acc[2][2][4][2];   // [P half][Q half][16-row P sub-tile][16-row Q sub-tile]
+    V8 PR[4][2], QA[2][2], QB[2][2];
 
     auto rdP = [&](int buf, int slot) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int ps = 0; ps < 4; ++ps)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) PR[s][ks] = *(const V8*)(smem + buf * BUF + slot + pr_off + s * 4096 + co[ks]);
+            for (int ks = 0; ks < 2; ++ks) PR[ps][ks] = *(const V8*)(smem + buf * BUF + slot + pr_off + ps * 2048 + co[ks]);
     };
-    auto rdQ = [&](V8 (&Q)[4], int buf, int slot) {
+    auto rdQ = [&](V8 (&Q)[2][2], int buf, int slot) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) Q[ks] = *(const V8*)(smem + buf * BUF + slot + q_off + co[ks]);
+        for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) Q[qs][ks] = *(const V8*)(smem + buf * BUF + slot + q_off + qs * 2048 + co[ks]);
     };
-    auto mma = [&](f32x16 (&c)[2], const V8 (&Q)[4]) {
+    auto mma = [&](f32x4 (&c)[4][2], const V8 (&Q)[2][2]) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) c[s] = Op<DT>::mfma32(PR[s][ks], Q[ks], c[s]);
+            for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) c[ps][qs] = Op<DT>::mfma16(PR[ps][ks], Q[qs][ks], c[ps][qs]);
         __builtin_amdgcn_s_setprio(0);
     };
 #define MHMR_SYNC()                          \
@@ -106,7 +110,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0)
 #define MHMR_WAIT_DMA() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 
-    // ---- prologue: tile 0 -> even buffer (all four halves), tile 1 -> odd buffer (Q0, P0) ----
+    const T *p_src, *q_src, *p_nxt, *q_nxt;
+    int p0, q0, p0n, q0n;
+    if (first >= ntiles) return;             // (never with the launcher's grid; keeps barrier counts trivially equal)
+    tile_src(first, p_src, q_src, p0, q0);
+
+    // ---- prologue (first tile only): K tile 0 -> even buffer (all four halves), K tile 1 -> odd buffer (Q0, P0) ----
     dma(q_src, ldq, 0, 0, SLOT_Q0);
     dma(p_src, ldp, 0, 0, SLOT_P0);
     dma(q_src, ldq, 1, 0, SLOT_Q1);
@@ -115,142 +124,168 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     dma(p_src, ldp, 0, 1, BUF + SLOT_P0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MHMR_SYNC();
-    if (wp == 1) { MHMR_SYNC(); }           // stagger: group 1 runs one barrier behind group 0
 
-    for (int t = 0; t < nt; t += 2) {
-        const int t1 = t + 1, t2 = t + 2, t3 = t + 3;
-        // phase 1
-        rdP(0, SLOT_P0); rdQ(QA, 0, SLOT_Q0);
-        dma(q_src, ldq, 1, t1, BUF + SLOT_Q1); MHMR_WAIT_DMA();
-        MHMR_SYNC(); mma(acc[0][0], QA); MHMR_SYNC();
-        // phase 2
-        rdQ(QB, 0, SLOT_Q1);
-        dma(p_src, ldp, 1, t1, BUF + SLOT_P1); MHMR_WAIT_DMA();
-        MHMR_SYNC(); mma(acc[0][1], QB); MHMR_SYNC();
-        // phase 3
-        rdP(0, SLOT_P1);
-        dma(q_src, ldq, 0, t2, SLOT_Q0); MHMR_WAIT_DMA();
-        MHMR_SYNC(); mma(acc[1][1], QB); MHMR_SYNC();
-        // phase 4
-        dma(p_src, ldp, 0, t2, SLOT_P0); MHMR_WAIT_DMA();
-        MHMR_SYNC(); mma(acc[1][0], QA); MHMR_SYNC();
-        // phase 5
-        rdP(1, SLOT_P0); rdQ(QA, 1, SLOT_Q0);
-        dma(q_src, ldq, 1, t2, SLOT_Q1); MHMR_WAIT_DMA();
-        MHMR_SYNC(); mma(acc[0][0], QA); MHMR_SYNC();
-        // phase 6
-        rdQ(QB, 1, SLOT_Q1);
-        dma(p_src, ldp, 1, t2, SLOT_P1); MHMR_WAIT_DMA();
-        MHMR_SYNC(); mma(acc[0][1], QB); MHMR_SYNC();
-        // phase 7
-        rdP(1, SLOT_P1);
-        dma(q_src, ldq, 0, t3, BUF + SLOT_Q0); MHMR_WAIT_DMA();
-        MHMR_SYNC(); mma(acc[1][1], QB); MHMR_SYNC();
-        // phase 8
-        dma(p_src, ldp, 0, t3, BUF + SLOT_P0); MHMR_WAIT_DMA();
-        MHMR_SYNC(); mma(acc[1][0], QA); MHMR_SYNC();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (wp == 0) { MHMR_SYNC(); }           // re-align the two groups
-    __syncthreads();                        // all DMA landed, all fragment reads done: LDS is free for the epilogue
-#undef MHMR_SYNC
-#undef MHMR_WAIT_DMA
+    for (int tix = first; tix < ntiles; tix += G) {
+        if (wp == 1) { MHMR_SYNC(); }       // stagger: during the K loop group 1 runs one barrier behind group 0
+        const bool has_next = tix + G < ntiles;
+        if (has_next) tile_src(tix + G, p_nxt, q_nxt, p0n, q0n);
+        else { p_nxt = p_src; q_nxt = q_src; p0n = p0; q0n = q0; }     // last tile: harmless re-load into slots nobody reads
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+                    for (int qs = 0; qs < 2; ++qs) acc[a][bb][ps][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- epilogue: per quadrant, transpose the wave's [32 Q-rows][64 P-cols] block through a private 8 KiB LDS
-    //      region so that global accesses are whole contiguous row segments ----
-    char* wl = smem + w * 8192;
-    constexpr bool OUT16 = (EPI == EPI_OP16 || EPI == EPI_OP16_GELU || EPI == EPI_OP16_RELU || EPI == EPI_VT);
+        for (int t = 0; t < nt; t += 2) {
+            // K-tile indices past the end of this tile are the first K tiles of the next one
+            const bool wrap = t + 2 >= nt;
+            const T* p2 = wrap ? p_nxt : p_src;
+            const T* q2 = wrap ? q_nxt : q_src;
+            const int t1 = t + 1, t2 = wrap ? (has_next ? 0 : nt - 1) : t + 2, t3 = wrap ? (has_next ? 1 : nt - 1) : t + 3;
+            // phase 1
+            rdP(0, SLOT_P0); rdQ(QA, 0, SLOT_Q0);
+            dma(q_src, ldq, 1, t1, BUF + SLOT_Q1); MHMR_WAIT_DMA();
+            MHMR_SYNC(); mma(acc[0][0], QA); MHMR_SYNC();
+            // phase 2
+            rdQ(QB, 0, SLOT_Q1);
+            dma(p_src, ldp, 1, t1, BUF + SLOT_P1); MHMR_WAIT_DMA();
+            MHMR_SYNC(); mma(acc[0][1], QB); MHMR_SYNC();
+            // phase 3
+            rdP(0, SLOT_P1);
+            dma(q2, ldq, 0, t2, SLOT_Q0); MHMR_WAIT_DMA();
+            MHMR_SYNC(); mma(acc[1][1], QB); MHMR_SYNC();
+            // phase 4
+            dma(p2, ldp, 0, t2, SLOT_P0); MHMR_WAIT_DMA();
+            MHMR_SYNC(); mma(acc[1][0], QA); MHMR_SYNC();
+            // phase 5
+            rdP(1, SLOT_P0); rdQ(QA, 1, SLOT_Q0);
+            dma(q2, ldq, 1, t2, SLOT_Q1); MHMR_WAIT_DMA();
+            MHMR_SYNC(); mma(acc[0][0], QA); MHMR_SYNC();
+            // phase 6
+            rdQ(QB, 1, SLOT_Q1);
+            dma(p2, ldp, 1, t2, SLOT_P1); MHMR_WAIT_DMA();
+            MHMR_SYNC(); mma(acc[0][1], QB); MHMR_SYNC();
+            // phase 7
+            rdP(1, SLOT_P1);
+            dma(q2, ldq, 0, t3, BUF + SLOT_Q0); MHMR_WAIT_DMA();
+            MHMR_SYNC(); mma(acc[1][1], QB); MHMR_SYNC();
+            // phase 8
+            dma(p2, ldp, 0, t3, BUF + SLOT_P0); MHMR_WAIT_DMA();
+            MHMR_SYNC(); mma(acc[1][0], QA); MHMR_SYNC();
+        }
+
+        if (wp == 0) { MHMR_SYNC(); }       // re-align: both groups run the memory-bound epilogue together
+        // ---- epilogue (wave-private staging; the next tile's DMA is in flight underneath) ----
+        // per quadrant, the wave's [32 Q-rows][64 P-cols] block is transposed through LDS so that global accesses are
+        // whole contiguous row segments (a direct store from the MFMA layout camps on one memory channel).
+        char* wl = smem + STAGE_OFF + w * 4096;
+        constexpr bool OUT16 = (EPI == EPI_OP16 || EPI == EPI_OP16_GELU || EPI == EPI_OP16_RELU || EPI == EPI_VT);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int pb = p0 + 128 * h + 64 * wp;      // first P index of the block (n for row-major, token for V^T)
-            const int qb = q0 + 128 * j + 32 * wq;      // first Q index (m for row-major, channel for V^T)
-            if constexpr (OUT16) {
+            for (int j = 0; j < 2; ++j) {
+                const int pb = p0 + 128 * h + 64 * wp;      // first P index of the block (n for row-major, token for V^T)
+                const int qb = q0 + 128 * j + 32 * wq;      // first Q index (m for row-major, channel for V^T)
+                if constexpr (OUT16) {
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const int pc = 32 * s + 8 * rg + 4 * hi;
+                    for (int ps = 0; ps < 4; ++ps) {
+                        const int pc = 16 * ps + 4 * g4;    // lane owns P columns pc..pc+3 of Q rows 16*qs + l15
                         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                        if (g.bias) {
-                            if constexpr (ROWMAJOR) bv = *(const f32x4*)(g.bias + pb + pc);
-                            else { const float b1 = g.bias[qb + l31]; bv = (f32x4){b1, b1, b1, b1}; }
-                        }
-                        V4 o;
+                        if constexpr (ROWMAJOR) { if (g.bias) bv = *(const f32x4*)(g.bias + pb + pc); }
+                        const int gs = ((g4 & 1) << 1) | (g4 >> 1);
+                        const int pos = ROWMAJOR ? pc : 16 * ps + 4 * gs;          // V^T: swap key bits 2 and 3
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = acc[h][j][s][4 * rg + e] + bv[e];
-                            if constexpr (EPI == EPI_OP16_GELU) v = gelu_fast(v);
-                            if constexpr (EPI == EPI_OP16_RELU) v = fmaxf(v, 0.f);
-                            o[e] = (T)v;
+                        for (int qs = 0; qs < 2; ++qs) {
+                            const int qr = 16 * qs + l15;
+                            if constexpr (!ROWMAJOR) { if (g.bias) { const float b1 = g.bias[qb + qr]; bv = (f32x4){b1, b1, b1, b1}; } }
+                            V4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float v = acc[h][j][ps][qs][e] + bv[e];
+                                if constexpr (EPI == EPI_OP16_GELU) v = gelu_fast(v);
+                                if constexpr (EPI == EPI_OP16_RELU) v = fmaxf(v, 0.f);
+                                o[e] = (T)v;
+                            }
+                            *(V4*)(wl + qr * 128 + (((pos >> 2) ^ ((qr & 7) << 1)) * 8)) = o;
                         }
-                        const int pos = ROWMAJOR ? pc : ((pc & ~12) | ((pc & 4) << 1) | ((pc & 8) >> 1));  // V^T: swap bits 2,3
-                        *(V4*)(wl + l31 * 128 + (((pos >> 2) ^ ((l31 & 7) << 1)) * 8)) = o;
                     }
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int row = 8 * it + (lane >> 3), c16 = lane & 7;
-                    const u32x4 v = *(const u32x4*)(wl + row * 128 + ((c16 ^ (row & 7)) * 16));
-                    if constexpr (ROWMAJOR) {
-                        *(u32x4*)((T*)g.out + (size_t)(qb + row) * g.ldo + pb + c16 * 8) = v;
-                    } else {
-                        const int n = qb + row, b = pb / g.Tp, tl = pb - b * g.Tp;
-                        *(u32x4*)((T*)g.out + ((size_t)(b * g.H + (n >> 6)) * 64 + (n & 63)) * g.Tp + tl + c16 * 8) = v;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const int ch = 8 * s + 2 * rg + hi;
-                        f32x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[h][j][s][4 * rg + e];
-                        *(f32x4*)(wl + l31 * 256 + ((ch ^ (l31 & 15)) * 16)) = v;
-                    }
-                const int c = lane & 15;
-                const int n = pb + 4 * c;
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gm = {1.f, 1.f, 1.f, 1.f};
-                if (g.bias) bv = *(const f32x4*)(g.bias + n);
-                if constexpr (EPI == EPI_RESID) gm = *(const f32x4*)(g.gamma + n);
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int row = 4 * it + (lane >> 4);
-                    f32x4 v = *(const f32x4*)(wl + row * 256 + ((c ^ (row & 15)) * 16)) + bv;
-                    const int m = qb + row;
-                    if constexpr (EPI == EPI_RESID) {
-                        float* op = (float*)g.out + (size_t)m * g.ldo + n;
-                        *(f32x4*)op = *(const f32x4*)op + gm * v;
-                    } else if constexpr (EPI == EPI_PATCH) {
-                        if (m < g.Mvalid) {
-                            const int b = m / g.Np, n_in = m - b * g.Np;
-                            v += *(const f32x4*)(g.pos + (size_t)(1 + n_in) * g.N + n);
-                            *(f32x4*)((float*)g.out + ((size_t)b * g.Tp + 1 + n_in) * g.ldo + n) = v;
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = 8 * it + (lane >> 3), c16 = lane & 7;
+                        const u32x4 v = *(const u32x4*)(wl + row * 128 + ((c16 ^ (row & 7)) * 16));
+                        if constexpr (ROWMAJOR) {
+                            *(u32x4*)((T*)g.out + (size_t)(qb + row) * g.ldo + pb + c16 * 8) = v;
+                        } else {
+                            const int n = qb + row, bi = pb / g.Tp, tl = pb - bi * g.Tp;
+                            *(u32x4*)((T*)g.out + ((size_t)(bi * g.H + (n >> 6)) * 64 + (n & 63)) * g.Tp + tl + c16 * 8) = v;
                         }
-                    } else {
-                        *(f32x4*)((float*)g.out + (size_t)m * g.ldo + n) = v;
+                    }
+                } else {
+                    const int c = lane & 15;
+                    const int n = pb + 4 * c;
+                    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gm = {1.f, 1.f, 1.f, 1.f};
+                    if (g.bias) bv = *(const f32x4*)(g.bias + n);
+                    if constexpr (EPI == EPI_RESID) gm = *(const f32x4*)(g.gamma + n);
+#pragma unroll
+                    for (int qs = 0; qs < 2; ++qs) {      // 16 Q-rows x 64 P-cols x 4 B = 4 KiB per pass
+#pragma unroll
+                        for (int ps = 0; ps < 4; ++ps) {
+                            const int ch = 4 * ps + g4;
+                            *(f32x4*)(wl + l15 * 256 + ((ch ^ l15) * 16)) = acc[h][j][ps][qs];
+                        }
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const int row = 4 * it + (lane >> 4);
+                            f32x4 v = *(const f32x4*)(wl + row * 256 + ((c ^ row) * 16)) + bv;
+                            const int m = qb + 16 * qs + row;
+                            if constexpr (EPI == EPI_RESID) {
+                                float* op = (float*)g.out + (size_t)m * g.ldo + n;
+                                *(f32x4*)op = *(const f32x4*)op + gm * v;
+                            } else if constexpr (EPI == EPI_PATCH) {
+                                if (m < g.Mvalid) {
+                                    const int bi = m / g.Np, n_in = m - bi * g.Np;
+                                    v += *(const f32x4*)(g.pos + (size_t)(1 + n_in) * g.N + n);
+                                    *(f32x4*)((float*)g.out + ((size_t)bi * g.Tp + 1 + n_in) * g.ldo + n) = v;
+                                }
+                            } else {
+                                *(f32x4*)((float*)g.out + (size_t)m * g.ldo + n) = v;
+                            }
+                        }
                     }
                 }
             }
         }
+        // drain: the epilogue's stores and the (long landed) next-tile DMA; re-establishes exact vmcnt accounting
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p_src = p_nxt; q_src = q_nxt; p0 = p0n; q0 = q0n;
     }
+#undef MHMR_SYNC
+#undef MHMR_WAIT_DMA
 }
 
 template <int DT>
 int launch256_dt(const GemmArgs& g, hipStream_t s) {
-    const int grid = (g.M / 256) * (g.N / 256);
-    const size_t lds = 2 * BUF;
+    const int ntiles = (g.M / 256) * (g.N / 256);
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MHMR_ERR_BAD_ARG;
+        ncu = prop.multiProcessorCount;
+    }
+    const int grid = ntiles < ncu ? ntiles : ncu;      // one persistent block per CU
 #define MHMR_GEMM_CASE(E)                                                                                      \
     case E: {                                                                                                  \
         static bool attr_set = false;                                                                          \
         if (!attr_set) {                                                                                       \
             (void)hipFuncSetAttribute((const void*)gemm256_kernel<DT, E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)lds);                                                               \
+                                      LDS_BYTES);                                                              \
             attr_set = true;                                                                                   \
         }                                                                                                      \
-        hipLaunchKernelGGL((gemm256_kernel<DT, E>), dim3(grid), dim3(512), lds, s, g);                         \
+        hipLaunchKernelGGL((gemm256_kernel<DT, E>), dim3(grid), dim3(512), LDS_BYTES, s, g);                   \
         break;                                                                                                 \
     }
     switch (g.epi) {

@@ -13,6 +13,7 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -29,6 +30,9 @@ template <> struct Op<MHMR_DT_BF16> {
     static __device__ __forceinline__ f32x16 mfma32(V8 a, V8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x4 mfma16(V8 a, V8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
 };
 template <> struct Op<MHMR_DT_F16> {
     typedef _Float16 T;
@@ -37,6 +41,9 @@ template <> struct Op<MHMR_DT_F16> {
     typedef f16x2 V2;
     static __device__ __forceinline__ f32x16 mfma32(V8 a, V8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(V8 a, V8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
 };
 

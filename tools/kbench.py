@@ -1,0 +1,72 @@
+#!/usr/bin/env python
+"""Kernel micro-benchmarks at the ViT-L 896x896 batch-32 shapes (random data): the four ViT GEMMs, attention,
+LayerNorm.  Prints one line per kernel: ms, TFLOP/s (algorithmic, T not Tp) or TB/s.
+usage: python tools/kbench.py [--dtype bf16|f16] [--only attn|gemm|ln] [--iters 10] [--batch 32]"""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multi_hmr_amd import _lib  # noqa: E402
+
+
+def timeit(fn, iters):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(iters):
+        fn()
+    ev[1].record()
+    torch.cuda.synchronize()
+    return ev[0].elapsed_time(ev[1]) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--only", default="")
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--img", type=int, default=896)
+    a = ap.parse_args()
+    L = _lib.lib()
+    dt, tdt = (_lib.DT_F16, torch.float16) if a.dtype == "f16" else (_lib.DT_BF16, torch.bfloat16)
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    B, C, H = a.batch, 1024, 16
+    G = a.img // 14
+    T = G * G + 1
+    Tp = (T + 127) // 128 * 128
+    M = B * Tp
+    rnd = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(tdt)
+    if a.only in ("", "gemm"):
+        shapes = [("qk   (EPI_OP16)", 2 * C, C, _lib.EPI_OP16), ("v    (EPI_VT)", C, C, _lib.EPI_VT), ("proj (EPI_RESID)", C, C, _lib.EPI_RESID),
+                  ("fc1  (EPI_GELU)", 4 * C, C, _lib.EPI_OP16_GELU), ("fc2  (EPI_RESID)", C, 4 * C, _lib.EPI_RESID)]
+        for name, N, K, epi in shapes:
+            A, W = rnd(M, K), (torch.randn(N, K, device=dev) / math.sqrt(K)).to(tdt)
+            bias, gamma = torch.randn(N, device=dev), torch.randn(N, device=dev)
+            out = torch.zeros(M * N, dtype=torch.float32 if epi == _lib.EPI_RESID else tdt, device=dev)
+            fn = lambda: _lib.check(L.mhmr_gemm16(A.data_ptr(), K, W.data_ptr(), K, M, N, K, bias.data_ptr(), gamma.data_ptr(), out.data_ptr(),
+                                                  N, None, 0, Tp, H, M, epi, dt, st), "gemm")
+            ms = timeit(fn, a.iters)
+            print(f"gemm {name:18s} M={M} N={N} K={K}: {ms:8.4f} ms  {2.0 * B * T * N * K / ms / 1e9:8.1f} TFLOP/s (alg)  {2.0 * M * N * K / ms / 1e9:8.1f} (padded)")
+    if a.only in ("", "attn"):
+        qk, vt, out = rnd(M, 2 * C), rnd(B * H * 64, Tp), torch.zeros(M, C, dtype=tdt, device=dev)
+        fn = lambda: _lib.check(L.mhmr_attention16(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), B, T, Tp, C, H, dt, st), "attn")
+        ms = timeit(fn, a.iters)
+        print(f"attention B={B} H={H} T={T}: {ms:8.4f} ms  {4.0 * B * H * T * T * 64 / ms / 1e9:8.1f} TFLOP/s (alg)")
+    if a.only in ("", "ln"):
+        x, w, b = torch.randn(M, C, device=dev), torch.randn(C, device=dev), torch.randn(C, device=dev)
+        o = torch.zeros(M, C, dtype=tdt, device=dev)
+        fn = lambda: _lib.check(L.mhmr_layernorm16(x.data_ptr(), w.data_ptr(), b.data_ptr(), o.data_ptr(), M, C, 1e-6, dt, st), "ln")
+        ms = timeit(fn, a.iters)
+        print(f"layernorm rows={M}: {ms:8.4f} ms  {M * C * 6 / ms / 1e9:8.2f} TB/s")
+
+
+if __name__ == "__main__":
+    main()
