@@ -169,6 +169,16 @@ int mhmr_hph_forward(const mhmr_hph_desc* d, const float* feat32, const float* z
                      const int* chunks, int nchunks, const float* K, int B, float* offset, float* loc, float* rotmat,
                      float* rotvec, float* betas, float* expr, float* dist_pp, float* dist, void* stream);
 
+/* The decoder layer stack alone: `depth` x (self-attention among the queries of one image, cross-attention over the
+ * image's N context tokens, GELU feed-forward), pre-norm, residual.  Replaces TransformerCrossAttn.forward of BOTH
+ * blocks/cross_attn_transformer.py:239-261 (dim 1024 / 8 heads / mlp 1024 / depth 2) and the Anny variant
+ * multi_hmr_anny/hph.py:114-151 (dim 512 / 16 heads / mlp 2048 / depth 8, context_dim = dim).  x [P, dim] is updated in
+ * place; ctx16 op16 [roundup(B*N,128), Kc]; workspaces xn [P,dim], t1 [P, max(3*32*heads, mlp)], t2 [P, 32*heads],
+ * kv [roundup(B*N,128), 64*heads] fp32; gstart / chunks as in mhmr_hph_forward.                                   */
+int mhmr_xattn_layers_forward(const mhmr_hph_layer* layers, int depth, int dim, int heads, int mlp, int Kc, int N, int B,
+                              int dtype, float* x, float* xn, float* t1, float* t2, float* kv, const void* ctx16,
+                              const int* gstart, int ngroups, int nmax, const int* chunks, int nchunks, int P, void* stream);
+
 /* Building blocks (unit tests). */
 int mhmr_linear_f32(const float* X, int ldx, const int* row_idx, const float* W, int ldw, const float* bias,
                     const float* R, int ldr, float* Y, int ldy, int M, int N, int K, int act, void* stream);

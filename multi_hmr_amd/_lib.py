@@ -84,6 +84,7 @@ _SIGS = {
     "mhmr_camera_embed": ([_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp], _i),
     "mhmr_hph_forward": ([C.POINTER(HphDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i,
                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "mhmr_xattn_layers_forward": ([C.POINTER(HphLayer)] + [_i] * 8 + [_vp] * 7 + [_i, _i, _vp, _i, _i, _vp], _i),
     "mhmr_linear_f32": ([_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "mhmr_layernorm_f32": ([_vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
     "mhmr_lbs_forward": ([C.POINTER(LbsConsts)] + [_vp] * 7 + [_i] + [_vp] * 8 + [_vp], _i),

@@ -8,8 +8,11 @@
 // already transposed and key-permuted (bits 2<->3 of the key index swapped inside every 16-key group, written
 // that way by the V GEMM epilogue), so the lane that holds P for keys {16s+4hi+0..3, 16s+8+4hi+0..3} reads the
 // matching V^T operand as ONE ds_read_b128 -- no cross-lane shuffle and no LDS transpose.
-// K and V^T tiles ([64][64] 16-bit = 128-byte rows) are DMA'd by global_load_lds_dwordx4 into double-buffered
-// LDS with the chunk XOR swizzle on the source address; one barrier per KV tile.
+// K and V^T tiles ([64][64] 16-bit = 128-byte rows) are DMA'd by global_load_lds_dwordx4 into a 3-slot LDS ring with
+// the chunk XOR swizzle on the source address, two tiles ahead; one barrier per KV tile.  The landing wait is an
+// EXPLICIT counted `s_waitcnt vmcnt(4)` (= everything but the newest tile's four DMA instructions): inside a loop hipcc
+// (ROCm 7.2) does NOT emit the vmcnt wait for LDS-DMA in front of __syncthreads() -- it hoisted it out of the loop -- and
+// the kernel then read tiles that had not landed (run-to-run different results; tools/determinism.py).
 #include "mhmr_common.h"
 #include "mhmr_internal.h"
 
@@ -25,7 +28,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const void* __restrict__ q
     typedef typename Op<DT>::T Tt;
     typedef typename Op<DT>::V8 V8;
     typedef typename Op<DT>::V4 V4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | Vt tile]
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [3][K tile | Vt tile]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,10 +79,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const void* __restrict__ q
 
     const int ntile = (T + KB - 1) / KB;
     stage(0, 0);
+    stage(ntile > 1 ? 1 : 0, 1);                 // (a 1-tile problem re-loads tile 0: keeps the counted wait uniform)
+    int buf = 0, nbuf = 2;                       // ring slot of tile j, and of tile j + 2
     for (int j = 0; j < ntile; ++j) {
-        __syncthreads();
-        if (j + 1 < ntile) stage(j + 1, (j + 1) & 1);
-        const char* sk = smem + (j & 1) * (2 * KV_TILE_BYTES);
+        // tile j has landed (only tile j+1's four DMA instructions may still be in flight); after the barrier every wave's
+        // part of it is visible and the slot of tile j-1 is free for tile j+2
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        stage(j + 2 < ntile ? j + 2 : ntile - 1, nbuf);   // tail: harmless re-load, keeps the wait count uniform
+        const char* sk = smem + buf * (2 * KV_TILE_BYTES);
+        buf = buf == 2 ? 0 : buf + 1;
+        nbuf = nbuf == 2 ? 0 : nbuf + 1;
         const char* sv = sk + KV_TILE_BYTES;
 
         // ---- S^T = K . Q^T ----
@@ -144,6 +155,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const void* __restrict__ q
         }
     }
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- normalise and store: lane (q, hi) holds O[q][32 ds + 8 rg + 4 hi + 0..3] ----
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
@@ -166,7 +178,7 @@ int mhmr_launch_attention(const void* qk, const void* vt, void* out, int B, int 
     if (C != H * 64 || Tp % QB || T > Tp || T <= 0) return MHMR_ERR_BAD_SHAPE;
     const int nqt = Tp / QB;
     const int grid = nqt * H * B;
-    const size_t lds = 4 * KV_TILE_BYTES;
+    const size_t lds = 6 * KV_TILE_BYTES;
     const float scale_log2e = 0.125f * 1.44269504088896340736f;
     prof_begin(PROF_ATTN, s);
     if (dtype == MHMR_DT_F16)

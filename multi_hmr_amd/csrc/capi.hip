@@ -178,6 +178,43 @@ int mhmr_layernorm_f32(const float* in, const float* w, const float* b, float* o
     return mhmr_launch_layernorm_f32(in, w, b, out, rows, C, eps, (hipStream_t)stream);
 }
 
+// `depth` x (pre-norm self-attention among the queries of one image, cross-attention over that image's N context
+// tokens, GELU feed-forward), each with a residual.  Shared by the Multi-HMR HPH (dim 1024, 8 heads, mlp 1024, depth 2,
+// blocks/cross_attn_transformer.py:239-261) and the Anny HPH (dim 512, 16 heads, mlp 2048, depth 8,
+// multi_hmr_anny/hph.py:114-151).  Queries are ragged groups (no padding), so the reference's mask arithmetic vanishes.
+int mhmr_xattn_layers_forward(const mhmr_hph_layer* layers, int depth, int dim, int heads, int mlp, int Kc, int N, int B,
+                              int dtype, float* x, float* xn, float* t1, float* t2, float* kv, const void* ctx16,
+                              const int* gstart, int ngroups, int nmax, const int* chunks, int nchunks, int P, void* stream) {
+    if (!layers || P < 0 || depth < 0) return MHMR_ERR_BAD_ARG;
+    if (P == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int inner = heads * 32;
+    if (Kc % 64 || dim % 64 || dim > 2048 || mlp % 16 || (2 * inner) % 128) return MHMR_ERR_BAD_SHAPE;
+    const int Mctx = (B * N + 127) / 128 * 128;
+    for (int l = 0; l < depth; ++l) {
+        const mhmr_hph_layer& L = layers[l];
+        // self-attention among the queries of one image
+        TRY(mhmr_launch_layernorm_f32(x, L.ln_sa_w, L.ln_sa_b, xn, P, dim, 1e-5f, s));
+        TRY(mhmr_launch_linear_f32(xn, dim, nullptr, L.to_qkv, dim, nullptr, nullptr, 0, t1, 3 * inner, P, 3 * inner, dim, MHMR_ACT_NONE, s));
+        TRY(mhmr_launch_hph_self_attn(t1, gstart, t2, ngroups, nmax, heads, s));
+        TRY(mhmr_launch_linear_f32(t2, inner, nullptr, L.sa_out_w, inner, L.sa_out_b, x, dim, x, dim, P, dim, inner, MHMR_ACT_NONE, s));
+        // cross-attention over the (un-normalised) per-image context
+        {
+            GemmArgs g{ctx16, Kc, L.to_kv16, Kc, Mctx, 2 * inner, Kc, nullptr, nullptr, kv, 2 * inner, nullptr, 0, 128, 1, Mctx, EPI_F32};
+            TRY(mhmr_launch_gemm(g, dtype, s));
+        }
+        TRY(mhmr_launch_layernorm_f32(x, L.ln_ca_w, L.ln_ca_b, xn, P, dim, 1e-5f, s));
+        TRY(mhmr_launch_linear_f32(xn, dim, nullptr, L.to_q, dim, nullptr, nullptr, 0, t1, inner, P, inner, dim, MHMR_ACT_NONE, s));
+        TRY(mhmr_launch_hph_cross_attn(t1, kv, chunks, nchunks, t2, heads, N, s));
+        TRY(mhmr_launch_linear_f32(t2, inner, nullptr, L.ca_out_w, inner, L.ca_out_b, x, dim, x, dim, P, dim, inner, MHMR_ACT_NONE, s));
+        // feed-forward
+        TRY(mhmr_launch_layernorm_f32(x, L.ln_ff_w, L.ln_ff_b, xn, P, dim, 1e-5f, s));
+        TRY(mhmr_launch_linear_f32(xn, dim, nullptr, L.ff1_w, dim, L.ff1_b, nullptr, 0, t1, mlp, P, mlp, dim, MHMR_ACT_GELU, s));
+        TRY(mhmr_launch_linear_f32(t1, mlp, nullptr, L.ff2_w, mlp, L.ff2_b, x, dim, x, dim, P, dim, mlp, MHMR_ACT_NONE, s));
+    }
+    return 0;
+}
+
 int mhmr_hph_forward(const mhmr_hph_desc* d, const float* feat32, const float* zK, void* ctx16, const int* det_b,
                      const int* det_y, const int* det_x, int P, const int* gstart, int ngroups, int nmax, const int* chunks,
                      int nchunks, const float* K, int B, float* offset, float* loc, float* rotmat, float* rotvec, float* betas,
@@ -199,31 +236,9 @@ int mhmr_hph_forward(const mhmr_hph_desc* d, const float* feat32, const float* z
     // token embedding (+ pos_embedding folded into the bias)  (cross_attn_transformer.py:352-357)
     TRY(mhmr_launch_linear_f32(d->token, d->Ktok, nullptr, d->tok_w, d->Ktok, d->tok_b, nullptr, 0, d->x, dim, P, dim, d->Ktok,
                                MHMR_ACT_NONE, s));
-    for (int l = 0; l < d->depth; ++l) {
-        const mhmr_hph_layer& L = d->layers[l];
-        // self-attention among the queries of one image
-        TRY(mhmr_launch_layernorm_f32(d->x, L.ln_sa_w, L.ln_sa_b, d->xn, P, dim, 1e-5f, s));
-        TRY(mhmr_launch_linear_f32(d->xn, dim, nullptr, L.to_qkv, dim, nullptr, nullptr, 0, d->t1, 3 * inner, P, 3 * inner, dim,
-                                   MHMR_ACT_NONE, s));
-        TRY(mhmr_launch_hph_self_attn(d->t1, gstart, d->t2, ngroups, nmax, d->heads, s));
-        TRY(mhmr_launch_linear_f32(d->t2, inner, nullptr, L.sa_out_w, inner, L.sa_out_b, d->x, dim, d->x, dim, P, dim, inner,
-                                   MHMR_ACT_NONE, s));
-        // cross-attention over the (un-normalised) per-image context
-        {
-            GemmArgs g{ctx16, d->Kc, L.to_kv16, d->Kc, Mctx, 2 * inner, d->Kc, nullptr, nullptr, d->kv, 2 * inner, nullptr, 0, 128,
-                       1, Mctx, EPI_F32};
-            TRY(mhmr_launch_gemm(g, d->dtype, s));
-        }
-        TRY(mhmr_launch_layernorm_f32(d->x, L.ln_ca_w, L.ln_ca_b, d->xn, P, dim, 1e-5f, s));
-        TRY(mhmr_launch_linear_f32(d->xn, dim, nullptr, L.to_q, dim, nullptr, nullptr, 0, d->t1, inner, P, inner, dim, MHMR_ACT_NONE, s));
-        TRY(mhmr_launch_hph_cross_attn(d->t1, d->kv, chunks, nchunks, d->t2, d->heads, d->N, s));
-        TRY(mhmr_launch_linear_f32(d->t2, inner, nullptr, L.ca_out_w, inner, L.ca_out_b, d->x, dim, d->x, dim, P, dim, inner,
-                                   MHMR_ACT_NONE, s));
-        // feed-forward
-        TRY(mhmr_launch_layernorm_f32(d->x, L.ln_ff_w, L.ln_ff_b, d->xn, P, dim, 1e-5f, s));
-        TRY(mhmr_launch_linear_f32(d->xn, dim, nullptr, L.ff1_w, dim, L.ff1_b, nullptr, 0, d->t1, mlp, P, mlp, dim, MHMR_ACT_GELU, s));
-        TRY(mhmr_launch_linear_f32(d->t1, mlp, nullptr, L.ff2_w, mlp, L.ff2_b, d->x, dim, d->x, dim, P, dim, mlp, MHMR_ACT_NONE, s));
-    }
+    (void)Mctx; (void)inner; (void)mlp;
+    TRY(mhmr_xattn_layers_forward(d->layers, d->depth, dim, d->heads, d->mlp, d->Kc, d->N, B, d->dtype, d->x, d->xn, d->t1, d->t2, d->kv,
+                                  ctx16, gstart, ngroups, nmax, chunks, nchunks, P, stream));
     // read-outs + init (model.py:571-575), 6D -> rotmat -> rotvec, distance post-processing
     TRY(mhmr_launch_linear_f32(d->x, dim, nullptr, d->dec_w, dim, d->dec_b, nullptr, 0, d->dec, d->Ndec, P, d->Ndec, dim, MHMR_ACT_NONE, s));
     return mhmr_launch_hph_decode(d->dec, d->Ndec, d->nb, K, det_b, d->fn, d->nearness, rotmat, rotvec, betas, expr, dist_pp,

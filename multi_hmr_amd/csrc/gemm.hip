@@ -76,7 +76,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const int nt = g.K / BK;
     stage(0, 0);
     for (int t = 0; t < nt; ++t) {
-        __syncthreads();  // tile t landed (vmcnt(0) + barrier); everyone is done reading the other buffer
+        // tile t landed and everyone is done reading the other buffer.  The vmcnt wait is EXPLICIT: inside a loop hipcc
+        // (ROCm 7.2) does not emit it for LDS-DMA in front of __syncthreads() (it hoists it out of the loop).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
         const char* sb = smem + (t & 1) * (2 * TILE_BYTES);
 #pragma unroll

@@ -1,0 +1,69 @@
+"""-m gpu: size-independent properties at BASELINE.json's full sizes (ViT-L/14, 896x896; 160 persons for the SMPL-X layer),
+where the CPU oracle would take minutes: batch invariance (images are independent, model.py:229-349), run-to-run
+determinism (no atomics on the path), LBS linearity in the shape coefficients at zero pose."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from multi_hmr_amd import Model, _lib, packing, synthetic  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def model_896(smplx_data, mean_params):
+    m = Model(backbone="dinov2_vitl14", img_size=896, smplx_data=smplx_data, mean_params=mean_params, precision="f16")
+    m.load_state_dict(synthetic.make_state_dict("dinov2_vitl14", 896, seed=0, mean_params=mean_params), strict=True)
+    return m.to("cuda:0").eval()
+
+
+def test_vitl_896_batch_invariance_and_determinism(model_896):
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    x = torch.randn(3, 3, 896, 896, generator=g, device="cuda:0")
+    K = synthetic.get_camera_K(896, 3).cuda()
+    idx = tuple(t.cuda() for t in synthetic.make_pinned_idx(3, 64, 5, seed=1))
+    a = model_896(x, idx=idx, K=K, is_training=True)
+    b = model_896(x, idx=idx, K=K, is_training=True)
+    for k in ("scores", "v3d", "rotmat", "transl", "shape"):
+        assert torch.equal(a[k], b[k]), k                              # bit-exact run to run
+        assert torch.isfinite(a[k]).all(), k
+    assert a["v3d"].shape == (15, 10475, 3) and a["scores"].shape == (3, 64, 64, 1)
+    # image 1 alone == image 1 inside the batch (same rows, same accumulation order)
+    sel = idx[0] == 1
+    idx1 = (torch.zeros(int(sel.sum()), dtype=torch.long, device="cuda:0"), idx[1][sel], idx[2][sel], idx[3][sel])
+    c = model_896(x[1:2], idx=idx1, K=K[1:2], is_training=True)
+    for k in ("v3d", "rotmat", "transl", "shape", "expression", "loc"):
+        d = (c[k] - a[k][sel]).abs().max() / a[k][sel].abs().max()
+        assert float(d) < 1e-6, (k, float(d))
+    assert float((c["scores"][0] - a["scores"][1]).abs().max()) < 1e-6
+
+
+def test_lbs_160_persons_linear_in_betas_at_zero_pose(smplx_data):
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    pk = packing.pack_smplx(smplx_data, 10, dev)
+    cs = packing.lbs_consts_struct(pk)
+    P, V = 160, pk["V"]
+    g = torch.Generator(device=dev).manual_seed(0)
+    K = synthetic.get_camera_K(1288, 8).to(dev)
+    det_b = (torch.arange(P, device=dev, dtype=torch.int32) // 20).contiguous()
+    loc = torch.full((P, 2), 644.0, device=dev)
+    dist = torch.full((P, 1), 5.0, device=dev)
+    pose, expr = torch.zeros(P, 53, 3, device=dev), torch.zeros(P, 10, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(betas):
+        f = lambda *s: torch.zeros(*s, device=dev)
+        v3d, v2d, j3d, j2d, tr = f(P, V, 3), f(P, V, 2), f(P, 127, 3), f(P, 127, 2), f(P, 3)
+        ws = [f(packing.roundup(P, 16), pk["Kb"]), f(P, 55, 12), f(P, 24)]
+        _lib.check(L.mhmr_lbs_forward(C.byref(cs), pose.data_ptr(), betas.data_ptr(), expr.data_ptr(), loc.data_ptr(), dist.data_ptr(),
+                                      K.data_ptr(), det_b.data_ptr(), P, *[w.data_ptr() for w in ws], v3d.data_ptr(), v2d.data_ptr(),
+                                      j3d.data_ptr(), j2d.data_ptr(), tr.data_ptr(), st), "lbs")
+        return v3d - j3d[:, [15]]            # head-centred vertices (the layer recentres on the head joint)
+
+    b1, b2 = torch.randn(P, 10, generator=g, device=dev), torch.randn(P, 10, generator=g, device=dev)
+    v0, v1, v2, v12 = run(torch.zeros(P, 10, device=dev)), run(b1), run(b2), run(b1 + b2)
+    lhs, rhs = v12 - v0, (v1 - v0) + (v2 - v0)
+    assert float((lhs - rhs).abs().max()) < 5e-6
+    assert float((v1 - v0).abs().max()) > 1e-3
