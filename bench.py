@@ -47,6 +47,17 @@ def lbs_bytes(P, nb=10):
     return const + P * (764 + 10475 * 3 * 4 + 10475 * 2 * 4 + 127 * 5 * 4)
 
 
+def pmc_traffic():
+    """HBM/fabric bytes per GEMM launch (average over the ViT-L 896 b32 launches) from the committed rocprofv3 PMC passes
+    (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc runs, tools/pmc_traffic.py -> profiles/r01_pmc_traffic.json); counters
+    cannot be read from inside the timed process, so this is null when the summary is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f).get("_gemm_avg_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def prof_window(kind):
     _lib.check(_lib.lib().mhmr_prof_enable(kind), "prof_enable")
 
@@ -135,9 +146,11 @@ def main():
                                f"{q} pinned persons/image -> HPH (depth 2) -> SMPL-X LBS; image-sharded x{world}",
                    "global_batch": world * B, "parallelism": f"dp{world} (images)"},
         "mfma_utilisation_whole_forward": round((gemm_fl + attn_fl) * B * args.steps / dt / 1e12 / PEAK_MFMA_TFLOPS, 4),
-        "roofline": {"kernel": "gemm_kernel (128x128x64 tile, v_mfma_f32_32x32x16)", "bound": "mfma", "achieved": round(gemm_tf, 1),
-                     "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tf / PEAK_MFMA_TFLOPS, 4), "traffic": None,
-                     "launches": n_gemm, "avg_launch_ms": round(ms_gemm / max(n_gemm, 1), 4)},
+        "roofline": {"kernel": "gemm256_kernel (persistent 256x256x64 8-phase, v_mfma_f32_16x16x32; all ViT linears + heads)",
+                     "bound": "mfma", "achieved": round(gemm_tf, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(gemm_tf / PEAK_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
+                     "launches": n_gemm, "avg_launch_ms": round(ms_gemm / max(n_gemm, 1), 4),
+                     "algorithmic_flops_per_launch": round(gemm_fl * B * args.steps / max(n_gemm, 1))},
     }
 
     if rank == 0 and not args.no_extras:
