@@ -45,6 +45,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const void* __restrict__ q
 
     // ---- Q fragments (B operand: lane (q = l31, hi) holds Q[q][16 ks + 8 hi + 0..7]) ----
     const int q_row = qt * QB + 32 * w + l31;
+    const bool active = qt * QB + 32 * w < T;  // a wave whose 32 query rows are all padding (T = 64 n + 1: three of the four waves
+                                               // of every image's last workgroup) skips the arithmetic and stores zeros
     V8 qf[4];
     {
         const Tt* qp = qk + (row0 + q_row) * ldq + h * 64 + 8 * hi;
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const void* __restrict__ q
         nbuf = nbuf == 2 ? 0 : nbuf + 1;
         const char* sv = sk + KV_TILE_BYTES;
 
+        if (!active) continue;  // wave-uniform: the wave still stages its share of every tile and meets every barrier
         // ---- S^T = K . Q^T ----
         f32x16 s[2];
 #pragma unroll
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const void* __restrict__ q
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- normalise and store: lane (q, hi) holds O[q][32 ds + 8 rg + 4 hi + 0..3] ----
     const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l_tot;
+    const float inv = active ? 1.0f / l_tot : 0.f;
     Tt* op = (Tt*)out_ + (row0 + q_row) * C + h * 64 + 4 * hi;
 #pragma unroll
     for (int ds = 0; ds < 2; ++ds)
