@@ -8,9 +8,10 @@
 // already transposed and key-permuted (bits 2<->3 of the key index swapped inside every 16-key group, written
 // that way by the V GEMM epilogue), so the lane that holds P for keys {16s+4hi+0..3, 16s+8+4hi+0..3} reads the
 // matching V^T operand as ONE ds_read_b128 -- no cross-lane shuffle and no LDS transpose.
-// K and V^T tiles ([64][64] 16-bit = 128-byte rows) are DMA'd by global_load_lds_dwordx4 into a 3-slot LDS ring with
-// the chunk XOR swizzle on the source address, two tiles ahead; one barrier per KV tile.  The landing wait is an
-// EXPLICIT counted `s_waitcnt vmcnt(4)` (= everything but the newest tile's four DMA instructions): inside a loop hipcc
+// K and V^T tiles ([64][64] 16-bit = 128-byte rows) are DMA'd by global_load_lds_dwordx4 into a 2-slot LDS ring with
+// the chunk XOR swizzle on the source address, one tile ahead (the whole consume phase of tile j covers tile j+1's
+// flight); one barrier per KV tile; 32 KiB LDS and 114 VGPRs put 4 workgroups = 16 waves on a CU (measured +2.8 % over a
+// 3-slot ring at 3 workgroups/CU).  The landing wait is an EXPLICIT `s_waitcnt vmcnt(0)`: inside a loop hipcc
 // (ROCm 7.2) does NOT emit the vmcnt wait for LDS-DMA in front of __syncthreads() -- it hoisted it out of the loop -- and
 // the kernel then read tiles that had not landed (run-to-run different results; tools/determinism.py).
 #include "mhmr_common.h"
@@ -22,13 +23,13 @@ constexpr int QB = 128, KB = 64;
 constexpr int KV_TILE_BYTES = KB * 64 * 2;  // 8 KiB
 
 template <int DT>
-__global__ __launch_bounds__(256, 2) void attn_kernel(const void* __restrict__ qk_, const void* __restrict__ vt_,
+__global__ __launch_bounds__(256, 4) void attn_kernel(const void* __restrict__ qk_, const void* __restrict__ vt_,
                                                       void* __restrict__ out_, int T, int Tp, int C, int H,
                                                       int nqt, float scale_log2e) {
     typedef typename Op<DT>::T Tt;
     typedef typename Op<DT>::V8 V8;
     typedef typename Op<DT>::V4 V4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [3][K tile | Vt tile]
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | Vt tile]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,32 +82,32 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const void* __restrict__ q
 
     const int ntile = (T + KB - 1) / KB;
     stage(0, 0);
-    stage(ntile > 1 ? 1 : 0, 1);                 // (a 1-tile problem re-loads tile 0: keeps the counted wait uniform)
-    int buf = 0, nbuf = 2;                       // ring slot of tile j, and of tile j + 2
+    int buf = 0;
     for (int j = 0; j < ntile; ++j) {
-        // tile j has landed (only tile j+1's four DMA instructions may still be in flight); after the barrier every wave's
-        // part of it is visible and the slot of tile j-1 is free for tile j+2
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        // tile j has landed (this wave's part: vmcnt(0); every wave's: the barrier), and every wave is done reading tile j-1,
+        // whose slot takes tile j+1 while tile j is being consumed
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        stage(j + 2 < ntile ? j + 2 : ntile - 1, nbuf);   // tail: harmless re-load, keeps the wait count uniform
+        stage(j + 1 < ntile ? j + 1 : ntile - 1, buf ^ 1);   // tail: harmless re-load
         const char* sk = smem + buf * (2 * KV_TILE_BYTES);
-        buf = buf == 2 ? 0 : buf + 1;
-        nbuf = nbuf == 2 ? 0 : nbuf + 1;
+        buf ^= 1;
         const char* sv = sk + KV_TILE_BYTES;
 
         if (!active) continue;  // wave-uniform: the wave still stages its share of every tile and meets every barrier
         // ---- S^T = K . Q^T ----
-        f32x16 s[2];
+        f32x16 s[2];   // the two key halves alternate in issue order: back-to-back MFMAs never share an accumulator
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+        for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const V8 kf = *(const V8*)(sk + (32 * sub + l31) * 128 + (((2 * ks + hi) ^ fsw) * 16));
-                s[sub] = Op<DT>::mfma32(kf, qf[ks], s[sub]);
-            }
+        for (int ks = 0; ks < 4; ++ks) {
+            V8 kf[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) kf[sub] = *(const V8*)(sk + (32 * sub + l31) * 128 + (((2 * ks + hi) ^ fsw) * 16));
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) s[sub] = Op<DT>::mfma32(kf[sub], qf[ks], s[sub]);
         }
         // ---- mask keys >= T (only the last tile can contain them) ----
         if (j * KB + KB > T) {
@@ -181,7 +182,7 @@ int mhmr_launch_attention(const void* qk, const void* vt, void* out, int B, int 
     if (C != H * 64 || Tp % QB || T > Tp || T <= 0) return MHMR_ERR_BAD_SHAPE;
     const int nqt = Tp / QB;
     const int grid = nqt * H * B;
-    const size_t lds = 6 * KV_TILE_BYTES;
+    const size_t lds = 4 * KV_TILE_BYTES;   // 32 KiB -> 4 workgroups (16 waves) per CU at 114 VGPRs
     const float scale_log2e = 0.125f * 1.44269504088896340736f;
     prof_begin(PROF_ATTN, s);
     if (dtype == MHMR_DT_F16)
