@@ -248,7 +248,17 @@ int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s) {
     if (g.epi == EPI_VT && (g.Tp % BM || g.N % 64)) return MHMR_ERR_BAD_SHAPE;
     prof_begin(PROF_GEMM, s);
     int rc;
-    if (!g_force_gemm128 && mhmr_gemm256_eligible(g)) rc = mhmr_launch_gemm256(g, dtype, s);
+    if (!g_force_gemm128 && mhmr_gemm256_eligible(g)) {
+        GemmArgs g2 = g;
+        // The residual epilogue moves 512 KiB per tile and all CUs reach it together: the round's 134 MB burst runs at the HBM
+        // floor while the MFMAs idle.  Starting the CU quarters 0/1/2/3 quarter-periods apart interleaves the bursts with the
+        // other quarters' K loops (proj 0.375 -> 0.350 ms, fc2 0.967 -> 0.953 ms; bias/GELU/V^T epilogues measured no gain).
+        // Period estimate: 1.4 us per K tile + 18 us epilogue.  MHMR_STAGGER_PCT scales it (0 = off).
+        static const char* st = getenv("MHMR_STAGGER_PCT");
+        if (g.epi == EPI_RESID && (g.M / 256) * (g.N / 256) >= 1024)      // only when every CU walks several tiles
+            g2.stagger_ticks = (int)((g.K / 64 * 1.4 + 18.0) * 25.0 * (st ? atoi(st) : 100) / 100.0);
+        rc = mhmr_launch_gemm256(g2, dtype, s);
+    }
     else rc = dtype == MHMR_DT_F16 ? launch_dt<MHMR_DT_F16>(g, s) : launch_dt<MHMR_DT_BF16>(g, s);
     prof_end(PROF_GEMM, s, 2.0 * g.M * g.N * g.K);
     return rc;

@@ -113,6 +113,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     const T *p_src, *q_src, *p_nxt, *q_nxt;
     int p0, q0, p0n, q0n;
     if (first >= ntiles) return;             // (never with the launcher's grid; keeps barrier counts trivially equal)
+    if (g.stagger_ticks > 0) {       // CU quarters start 0/1/2/3 x stagger_ticks late so their epilogue bursts interleave (gemm.hip)
+        const uint64_t t0 = wall_clock64(), dl = (uint64_t)g.stagger_ticks * (uint64_t)(first * 4 / G);
+        while (wall_clock64() - t0 < dl) __builtin_amdgcn_s_sleep(32);
+    }
     tile_src(first, p_src, q_src, p0, q0);
 
     // ---- prologue (first tile only): K tile 0 -> even buffer (all four halves), K tile 1 -> odd buffer (Q0, P0) ----
@@ -183,6 +187,51 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         // whole contiguous row segments (a direct store from the MFMA layout camps on one memory channel).
         char* wl = smem + STAGE_OFF + w * 4096;
         constexpr bool OUT16 = (EPI == EPI_OP16 || EPI == EPI_OP16_GELU || EPI == EPI_OP16_RELU || EPI == EPI_VT);
+        if constexpr (EPI == EPI_RESID) {
+            // out32 += gamma * (acc + bias), in place.  8 passes (h, j, qs) of [16 rows][64 cols] fp32 per wave; a pass that
+            // loads its residual lines only when it needs them pays one HBM round trip per pass (8 in series: 22-25 us per
+            // tile).  The residual of pass s + 1 is requested before pass s is staged (registers: the operand fragments, dead
+            // between K loops): proj 0.414 -> 0.365 ms, fc2 1.01 -> 0.975 ms.  Deeper prefetch (2 passes, or growing as staged
+            // passes free their accumulators) measured no better: with every CU in its epilogue at once the 134 MB round is at
+            // the HBM floor.
+            constexpr int RD = 1;
+            const int c = lane & 15;
+            // 32-bit byte offsets from the uniform base (eligibility guarantees M * ldo * 4 < 2^32): one VGPR per address
+            const uint32_t off0 = ((uint32_t)(q0 + 32 * wq + (lane >> 4)) * (uint32_t)g.ldo + (uint32_t)(p0 + 64 * wp + 4 * c)) * 4u;
+            const uint32_t rstep = (uint32_t)g.ldo * 16u;          // 4 rows
+            auto rptr = [&](int sidx, int it) {
+                const int h = sidx >> 2, j = (sidx >> 1) & 1, qs = sidx & 1;
+                const uint32_t off = off0 + (uint32_t)(32 * j + 4 * qs + it) * rstep + (uint32_t)(512 * h);
+                return (f32x4*)((char*)g.out + off);
+            };
+            f32x4 r[8][4];
+#pragma unroll
+            for (int sidx = 0; sidx < RD; ++sidx)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) r[sidx][it] = *rptr(sidx, it);
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gm = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int sidx = 0; sidx < 8; ++sidx) {
+                const int h = sidx >> 2, j = (sidx >> 1) & 1, qs = sidx & 1;
+                if (sidx + RD < 8) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) r[sidx + RD][it] = *rptr(sidx + RD, it);
+                }
+                if ((sidx & 3) == 0) {
+                    const int n = p0 + 128 * h + 64 * wp + 4 * c;
+                    if (g.bias) bv = *(const f32x4*)(g.bias + n);
+                    gm = *(const f32x4*)(g.gamma + n);
+                }
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) *(f32x4*)(wl + l15 * 256 + (((4 * ps + g4) ^ l15) * 16)) = acc[h][j][ps][qs];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = 4 * it + (lane >> 4);
+                    const f32x4 v = *(const f32x4*)(wl + row * 256 + ((c ^ row) * 16)) + bv;
+                    *rptr(sidx, it) = r[sidx][it] + gm * v;
+                }
+            }
+        } else {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -258,6 +307,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                 }
             }
         }
+        }
         // drain: the epilogue's stores and the (long landed) next-tile DMA; re-establishes exact vmcnt accounting
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         p_src = p_nxt; q_src = q_nxt; p0 = p0n; q0 = q0n;
@@ -307,6 +357,7 @@ int launch256_dt(const GemmArgs& g, hipStream_t s) {
 }  // namespace
 
 bool mhmr_gemm256_eligible(const GemmArgs& g) {
+    if (g.epi == EPI_RESID && (uint64_t)g.M * (uint64_t)g.ldo * 4u >= (1ull << 32)) return false;   // 32-bit residual offsets
     return g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && (g.epi != EPI_VT || g.Tp % 64 == 0);
 }
 

@@ -24,6 +24,7 @@ struct GemmArgs {
     const float* pos;
     int Np, Tp, H, Mvalid;
     int epi;
+    int stagger_ticks = 0;   // gemm256: CU quarter q starts q * stagger_ticks (100 MHz wall clock) late
 };
 
 int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s);
