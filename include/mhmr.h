@@ -214,6 +214,21 @@ int mhmr_lbs_forward(const mhmr_lbs_consts* c, const float* rotvec, const float*
                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Input preprocessing, the step before Model.forward:
+ *   demo.py:27-51 open_image  = PIL ImageOps.contain(img, (S,S)) [bicubic, aspect kept] + ImageOps.pad(.., (S,S))
+ *                               [centred, black] + utils/image.py:12-24 normalize_rgb.
+ * img: decoded uint8 RGB [H][W][3] on the device.  The resample is Pillow's 8-bit two-pass convolution in its
+ * own fixed point (22 fractional bits), bit-identical to PIL: the host passes Pillow's coefficient tables
+ * (multi_hmr_amd/preprocess.py: kh [ow][ksh] / kv [oh][ksv] int32, bounds bh [ow][2] / bv [oh][2] = (first tap,
+ * tap count)) and the 3 x 256 normalisation table lut (the reference's numpy expression evaluated on 0..255).
+ * Only source rows y0 .. y0+rows-1 (those the vertical taps touch) are resampled horizontally into tmp
+ * [rows][ow][3] uint8.  out: [3][S][S] fp32, the resized image at (pad_x, pad_y), lut[c][0] elsewhere.
+ * ---------------------------------------------------------------------------------------------------------- */
+int mhmr_preprocess_u8(const void* img, int H, int W, const int* kh, const int* bh, int ksh, const int* kv,
+                       const int* bv, int ksv, int ow, int oh, int y0, int rows, int S, int pad_x, int pad_y,
+                       const float* lut, void* tmp, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Measurement: hipEvent brackets around every launch of one kernel family (0 = GEMM, 1 = attention, 2 = LBS
  * vertex kernel), recorded on the launch stream.  enable(kind >= 0) starts a fresh window, enable(-1) stops;
  * collect() synchronises the recorded events and returns launches, summed milliseconds and summed work

@@ -4,45 +4,13 @@ from __future__ import annotations
 
 import os
 
-import numpy as np
 import torch
 
 from .model import Model
 
+from .preprocess import IMG_NORM_MEAN, IMG_NORM_STD, get_camera_parameters, open_image  # noqa: F401  (demo.py:27-68 on the GPU)
+
 CACHE_DIR_MULTIHMR = "models/multiHMR"          # reference utils/constants.py:9
-IMG_NORM_MEAN = [0.485, 0.456, 0.406]           # reference utils/image.py:9-10
-IMG_NORM_STD = [0.229, 0.224, 0.225]
-
-
-def normalize_rgb(img):
-    """utils/image.py:12-24: uint8 HWC -> float32 CHW, ImageNet-normalised."""
-    img = img.astype(np.float32) / 255.0
-    img = np.transpose(img, (2, 0, 1))
-    img = (img - np.asarray(IMG_NORM_MEAN).reshape(3, 1, 1)) / np.asarray(IMG_NORM_STD).reshape(3, 1, 1)
-    return img.astype(np.float32)
-
-
-def open_image(img_path, img_size, device=torch.device("cuda")):
-    """demo.py:27-51: open, resize keeping the aspect ratio, zero-pad to a square, normalise."""
-    from PIL import Image, ImageOps
-    img_pil = Image.open(img_path).convert("RGB")
-    img_pil_full = img_pil.copy()
-    img_pil = ImageOps.contain(img_pil, (img_size, img_size))
-    img_pil = ImageOps.pad(img_pil, size=(img_size, img_size))
-    x = torch.from_numpy(normalize_rgb(np.asarray(img_pil))).unsqueeze(0).to(device)
-    return x, img_pil_full
-
-
-def get_camera_parameters(img_size, fov=60, p_x=None, p_y=None, device=torch.device("cuda")):
-    """demo.py:53-68."""
-    K = torch.eye(3)
-    focal = img_size / (2 * np.tan(np.radians(fov) / 2))
-    K[0, 0], K[1, 1] = focal, focal
-    if p_x is not None and p_y is not None:
-        K[0, -1], K[1, -1] = p_x * img_size, p_y * img_size
-    else:
-        K[0, -1], K[1, -1] = img_size // 2, img_size // 2
-    return K.unsqueeze(0).to(device)
 
 
 def load_model(model_name, device=torch.device("cuda"), **model_kwargs):
