@@ -229,6 +229,18 @@ int mhmr_preprocess_u8(const void* img, int H, int W, const int* kh, const int* 
                        const float* lut, void* tmp, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Accuracy metrics of the reference's evaluation loop, train.py:372-395 (PVE, PA-PVE) and
+ * 415-423 (MPJPE, PA-MPJPE): for M matched pairs of V points, pred / gt [M][V][3] fp32, optionally recentred by
+ * pred_center / gt_center [M][3] (the pelvis translations; NULL = none):
+ *   pve[m]    = mean_n |gt_n - pred_n| * 1000
+ *   pa_pve[m] = mean_n |gt_n - (s R pred_n + t)| * 1000,  (R, t, s) = roma.rigid_points_registration(pred, gt,
+ *               compute_scaling=True)  (proper rotation; scale = tr(R^T M) / sum |pred - mean|^2)
+ * Rts (nullable) [M][13] receives R (row-major 9), t (3), s.
+ * ---------------------------------------------------------------------------------------------------------- */
+int mhmr_eval_mesh_errors(const float* pred, const float* gt, const float* pred_center, const float* gt_center, int M,
+                          int V, float* pve, float* pa_pve, float* Rts, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Measurement: hipEvent brackets around every launch of one kernel family (0 = GEMM, 1 = attention, 2 = LBS
  * vertex kernel), recorded on the launch stream.  enable(kind >= 0) starts a fresh window, enable(-1) stops;
  * collect() synchronises the recorded events and returns launches, summed milliseconds and summed work

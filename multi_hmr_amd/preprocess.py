@@ -162,7 +162,7 @@ def open_image(img_path, img_size, device=torch.device("cuda")):
     key = (int(img_size), str(device))
     if key not in _PRE:
         _PRE[key] = Preprocessor(img_size, device)
-    x = _PRE[key](torch.from_numpy(np.asarray(img_pil)))
+    x = _PRE[key](torch.from_numpy(np.array(img_pil)))
     return x, img_pil.copy()
 
 

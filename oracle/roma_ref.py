@@ -81,3 +81,30 @@ def unitquat_to_rotvec(quat: torch.Tensor) -> torch.Tensor:
 
 def rotmat_to_rotvec(R: torch.Tensor) -> torch.Tensor:
     return unitquat_to_rotvec(rotmat_to_unitquat(R))
+
+
+def special_procrustes(M: torch.Tensor, return_singular_values: bool = False):
+    """roma.special_procrustes (restated from the published algorithm): R in SO(3) minimising |R - M|_F.
+    M = U S V^T  ->  R = U diag(1, 1, det(U V^T)) V^T;  the returned singular values carry the same sign on the last one."""
+    U, S, Vh = torch.linalg.svd(M)
+    d = torch.det(U @ Vh)
+    D = torch.ones_like(S)
+    D[..., -1] = d
+    R = (U * D.unsqueeze(-2)) @ Vh
+    return (R, S * D) if return_singular_values else R
+
+
+def rigid_points_registration(x: torch.Tensor, y: torch.Tensor, compute_scaling: bool = False):
+    """roma.rigid_points_registration (restated; call sites train.py:384, 420): (R, t, s) minimising sum |s R x_n + t - y_n|^2
+    over x, y [..., N, 3]."""
+    xmean, ymean = x.mean(dim=-2, keepdim=True), y.mean(dim=-2, keepdim=True)
+    xhat, yhat = x - xmean, y - ymean
+    M = yhat.transpose(-1, -2) @ xhat
+    if compute_scaling:
+        R, DS = special_procrustes(M, return_singular_values=True)
+        scale = DS.sum(-1) / (xhat ** 2).sum(dim=(-1, -2))
+        t = ymean.squeeze(-2) - scale.unsqueeze(-1) * (R @ xmean.transpose(-1, -2)).squeeze(-1)
+        return R, t, scale
+    R = special_procrustes(M)
+    t = ymean.squeeze(-2) - (R @ xmean.transpose(-1, -2)).squeeze(-1)
+    return R, t, None
