@@ -113,7 +113,7 @@ class Preprocessor:
         self.S = int(img_size)
         self.device = torch.device(device)
         if self.device.type != "cuda":
-            raise _lib.MhmrError("Preprocessor needs a HIP device: there is no CPU fallback (use demo.open_image for the PIL path)")
+            raise _lib.MhmrError("Preprocessor needs a HIP device: there is no CPU fallback")
         self.lut = torch.from_numpy(norm_lut()).to(self.device)
         self._tables = {}
 
