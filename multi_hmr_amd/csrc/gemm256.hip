@@ -110,6 +110,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0)
 #define MHMR_WAIT_DMA() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 
+    // The bias is the accumulators' initial value: the epilogue then has no bias loads at all (a global load there is followed by
+    // its s_waitcnt vmcnt(0), which also waits for every store already issued -- 16 serialized HBM round trips per tile).  The
+    // next tile's values are requested in the epilogue as each quadrant's accumulators are staged out, and land by its drain.
+    auto acc_init = [&](int h, int j, int qs, int pp0, int qq0) {
+        if constexpr (ROWMAJOR) {
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps)
+                acc[h][j][ps][qs] = g.bias ? *(const f32x4*)(g.bias + pp0 + 128 * h + 64 * wp + 16 * ps + 4 * g4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else {
+            const float b1 = g.bias ? g.bias[qq0 + 128 * j + 32 * wq + 16 * qs + l15] : 0.f;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) acc[h][j][ps][qs] = (f32x4){b1, b1, b1, b1};
+        }
+    };
+
     const T *p_src, *q_src, *p_nxt, *q_nxt;
     int p0, q0, p0n, q0n;
     if (first >= ntiles) return;             // (never with the launcher's grid; keeps barrier counts trivially equal)
@@ -126,6 +141,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     dma(p_src, ldp, 1, 0, SLOT_P1);
     dma(q_src, ldq, 0, 1, BUF + SLOT_Q0);
     dma(p_src, ldp, 0, 1, BUF + SLOT_P0);
+#pragma unroll
+    for (int a = 0; a < 8; ++a) acc_init(a >> 2, (a >> 1) & 1, a & 1, p0, q0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MHMR_SYNC();
 
@@ -134,15 +151,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         const bool has_next = tix + G < ntiles;
         if (has_next) tile_src(tix + G, p_nxt, q_nxt, p0n, q0n);
         else { p_nxt = p_src; q_nxt = q_src; p0n = p0; q0n = q0; }     // last tile: harmless re-load into slots nobody reads
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-                for (int ps = 0; ps < 4; ++ps)
-#pragma unroll
-                    for (int qs = 0; qs < 2; ++qs) acc[a][bb][ps][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
         for (int t = 0; t < nt; t += 2) {
             // K-tile indices past the end of this tile are the first K tiles of the next one
             const bool wrap = t + 2 >= nt;
@@ -209,7 +217,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
             for (int sidx = 0; sidx < RD; ++sidx)
 #pragma unroll
                 for (int it = 0; it < 4; ++it) r[sidx][it] = *rptr(sidx, it);
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gm = {1.f, 1.f, 1.f, 1.f};
+            f32x4 gm[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) gm[h] = *(const f32x4*)(g.gamma + p0 + 128 * h + 64 * wp + 4 * c);
 #pragma unroll
             for (int sidx = 0; sidx < 8; ++sidx) {
                 const int h = sidx >> 2, j = (sidx >> 1) & 1, qs = sidx & 1;
@@ -217,18 +227,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
 #pragma unroll
                     for (int it = 0; it < 4; ++it) r[sidx + RD][it] = *rptr(sidx + RD, it);
                 }
-                if ((sidx & 3) == 0) {
-                    const int n = p0 + 128 * h + 64 * wp + 4 * c;
-                    if (g.bias) bv = *(const f32x4*)(g.bias + n);
-                    gm = *(const f32x4*)(g.gamma + n);
-                }
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) *(f32x4*)(wl + l15 * 256 + (((4 * ps + g4) ^ l15) * 16)) = acc[h][j][ps][qs];
+                acc_init(h, j, qs, p0n, q0n);
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int row = 4 * it + (lane >> 4);
-                    const f32x4 v = *(const f32x4*)(wl + row * 256 + ((c ^ row) * 16)) + bv;
-                    *rptr(sidx, it) = r[sidx][it] + gm * v;
+                    const f32x4 v = *(const f32x4*)(wl + row * 256 + ((c ^ row) * 16));
+                    *rptr(sidx, it) = r[sidx][it] + gm[h] * v;
                 }
             }
         } else {
@@ -242,18 +248,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
 #pragma unroll
                     for (int ps = 0; ps < 4; ++ps) {
                         const int pc = 16 * ps + 4 * g4;    // lane owns P columns pc..pc+3 of Q rows 16*qs + l15
-                        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                        if constexpr (ROWMAJOR) { if (g.bias) bv = *(const f32x4*)(g.bias + pb + pc); }
                         const int gs = ((g4 & 1) << 1) | (g4 >> 1);
                         const int pos = ROWMAJOR ? pc : 16 * ps + 4 * gs;          // V^T: swap key bits 2 and 3
 #pragma unroll
                         for (int qs = 0; qs < 2; ++qs) {
                             const int qr = 16 * qs + l15;
-                            if constexpr (!ROWMAJOR) { if (g.bias) { const float b1 = g.bias[qb + qr]; bv = (f32x4){b1, b1, b1, b1}; } }
                             V4 o;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                float v = acc[h][j][ps][qs][e] + bv[e];
+                                float v = acc[h][j][ps][qs][e];
                                 if constexpr (EPI == EPI_OP16_GELU) v = gelu_fast(v);
                                 if constexpr (EPI == EPI_OP16_RELU) v = fmaxf(v, 0.f);
                                 o[e] = (T)v;
@@ -261,6 +264,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                             *(V4*)(wl + qr * 128 + (((pos >> 2) ^ ((qr & 7) << 1)) * 8)) = o;
                         }
                     }
+                    acc_init(h, j, 0, p0n, q0n);
+                    acc_init(h, j, 1, p0n, q0n);
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int row = 8 * it + (lane >> 3), c16 = lane & 7;
@@ -275,9 +280,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                 } else {
                     const int c = lane & 15;
                     const int n = pb + 4 * c;
-                    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gm = {1.f, 1.f, 1.f, 1.f};
-                    if (g.bias) bv = *(const f32x4*)(g.bias + n);
-                    if constexpr (EPI == EPI_RESID) gm = *(const f32x4*)(g.gamma + n);
 #pragma unroll
                     for (int qs = 0; qs < 2; ++qs) {      // 16 Q-rows x 64 P-cols x 4 B = 4 KiB per pass
 #pragma unroll
@@ -285,15 +287,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                             const int ch = 4 * ps + g4;
                             *(f32x4*)(wl + l15 * 256 + ((ch ^ l15) * 16)) = acc[h][j][ps][qs];
                         }
+                        acc_init(h, j, qs, p0n, q0n);
 #pragma unroll
                         for (int it = 0; it < 4; ++it) {
                             const int row = 4 * it + (lane >> 4);
-                            f32x4 v = *(const f32x4*)(wl + row * 256 + ((c ^ row) * 16)) + bv;
+                            f32x4 v = *(const f32x4*)(wl + row * 256 + ((c ^ row) * 16));
                             const int m = qb + 16 * qs + row;
-                            if constexpr (EPI == EPI_RESID) {
-                                float* op = (float*)g.out + (size_t)m * g.ldo + n;
-                                *(f32x4*)op = *(const f32x4*)op + gm * v;
-                            } else if constexpr (EPI == EPI_PATCH) {
+                            if constexpr (EPI == EPI_PATCH) {
                                 if (m < g.Mvalid) {
                                     const int bi = m / g.Np, n_in = m - bi * g.Np;
                                     v += *(const f32x4*)(g.pos + (size_t)(1 + n_in) * g.N + n);

@@ -4,8 +4,8 @@ import math, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multi_hmr_amd import _lib
 L = _lib.lib(); dev = torch.device("cuda:0"); st = torch.cuda.current_stream().cuda_stream
-B = int(os.environ.get("B", "3")); C, H = 1024, 16; T = 4097; Tp = 4224; M = B * Tp
-if M % 256: M = (M + 255) // 256 * 256
+B = int(os.environ.get("B", "4")); C, H = 1024, 16; T = 4097; Tp = 4224; M = B * Tp   # B * Tp must be a multiple of 256
+assert M % 256 == 0
 dt, tdt = _lib.DT_BF16, torch.bfloat16
 reps = int(os.environ.get("REPS", "6"))
 def check(name, fn, out_fn):

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--img", type=int, default=896)
+    ap.add_argument("--tp", type=int, default=0, help="override the padded token count per image (GEMM rows = batch * tp)")
     a = ap.parse_args()
     L = _lib.lib()
     dt, tdt = (_lib.DT_F16, torch.float16) if a.dtype == "f16" else (_lib.DT_BF16, torch.bfloat16)
@@ -41,7 +42,7 @@ def main():
     B, C, H = a.batch, 1024, 16
     G = a.img // 14
     T = G * G + 1
-    Tp = (T + 127) // 128 * 128
+    Tp = a.tp if a.tp else (T + 127) // 128 * 128
     M = B * Tp
     rnd = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(tdt)
     if a.only in ("", "gemm"):
