@@ -19,11 +19,12 @@
 
 namespace {
 
-constexpr int QB = 128, KB = 64;
+constexpr int KB = 64;
 constexpr int KV_TILE_BYTES = KB * 64 * 2;  // 8 KiB
 
-template <int DT>
-__global__ __launch_bounds__(256, 4) void attn_kernel(const void* __restrict__ qk_, const void* __restrict__ vt_,
+// NW waves x 32 query rows per workgroup; RING K/V tile slots in LDS (tile j + RING - 1 is in flight while tile j is consumed)
+template <int DT, int NW, int RING>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(const void* __restrict__ qk_, const void* __restrict__ vt_,
                                                       void* __restrict__ out_, int T, int Tp, int C, int H,
                                                       int nqt, float scale_log2e) {
     typedef typename Op<DT>::T Tt;
@@ -45,18 +46,22 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const void* __restrict__ q
     const size_t row0 = (size_t)b * Tp;
 
     // ---- Q fragments (B operand: lane (q = l31, hi) holds Q[q][16 ks + 8 hi + 0..7]) ----
+    constexpr int QB = 32 * NW;
     const int q_row = qt * QB + 32 * w + l31;
     const bool active = qt * QB + 32 * w < T;  // a wave whose 32 query rows are all padding (T = 64 n + 1: three of the four waves
                                                // of every image's last workgroup) skips the arithmetic and stores zeros
-    V8 qf[4];
-    {
+    const bool in_buf = qt * QB + 32 * w < Tp;   // QB = 256: the last workgroup's upper waves lie past the padded rows
+    V8 qf[4] = {};
+    if (in_buf) {
         const Tt* qp = qk + (row0 + q_row) * ldq + h * 64 + 8 * hi;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const V8*)(qp + 16 * ks);
     }
 
-    // ---- staging addresses ----
-    const int srow = tid >> 3;                                 // 0..31 (+32 on the second pass)
+    // ---- staging addresses: one glds16 per thread moves 64 * NW chunks of 16 B = 8 * NW tile rows ----
+    constexpr int PASSES = 8 / NW, ROWS_PER_PASS = 8 * NW;        // NW = 4: 2 passes of 32 rows; NW = 8: 1 pass of 64 rows
+    constexpr int OPS = 2 * PASSES;                                // DMA instructions per tile per thread
+    const int srow = tid >> 3;
     const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
     const Tt* k_src = qk + (row0 + srow) * ldq + C + h * 64 + schunk * 8;                 // + key0 * ldq
     const Tt* v_src = vt + ((size_t)(b * H + h) * 64 + srow) * Tp + schunk * 8;           // + key0
@@ -65,10 +70,10 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const void* __restrict__ q
         char* sv = sk + KV_TILE_BYTES;
         const Tt* kp = k_src + (size_t)j * KB * ldq;
         const Tt* vp = v_src + j * KB;
-        glds16(kp, sk);
-        glds16(kp + (size_t)32 * ldq, sk + 4096);
-        glds16(vp, sv);
-        glds16(vp + (size_t)32 * Tp, sv + 4096);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) glds16(kp + (size_t)(ROWS_PER_PASS * ps) * ldq, sk + ps * (ROWS_PER_PASS * 128));
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) glds16(vp + (size_t)(ROWS_PER_PASS * ps) * Tp, sv + ps * (ROWS_PER_PASS * 128));
     };
 
     const int fsw = (lane >> 1) & 7;
@@ -81,17 +86,24 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const void* __restrict__ q
     float m_run = -1e30f, l_run = 0.f;  // running max (scaled, log2 domain) and this lane's partial row sum
 
     const int ntile = (T + KB - 1) / KB;
-    stage(0, 0);
-    int buf = 0;
+#pragma unroll
+    for (int t = 0; t < RING - 1; ++t) stage(t < ntile ? t : ntile - 1, t);
+    int buf = 0, nbuf = RING - 1;                // ring slot of tile j, and of tile j + RING - 1
     for (int j = 0; j < ntile; ++j) {
-        // tile j has landed (this wave's part: vmcnt(0); every wave's: the barrier), and every wave is done reading tile j-1,
-        // whose slot takes tile j+1 while tile j is being consumed
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // tile j has landed (this wave's part: the counted vmcnt -- only the RING - 2 newer tiles may still be in flight; every
+        // wave's: the barrier), and every wave is done reading tile j-1, whose slot takes tile j + RING - 1
+        if constexpr (RING == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if constexpr (OPS * (RING - 2) == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else if constexpr (OPS * (RING - 2) == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if constexpr (OPS * (RING - 2) == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        static_assert(OPS * (RING - 2) <= 8, "extend the counted waits");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        stage(j + 1 < ntile ? j + 1 : ntile - 1, buf ^ 1);   // tail: harmless re-load
+        stage(j + RING - 1 < ntile ? j + RING - 1 : ntile - 1, nbuf);   // tail: harmless re-load, keeps the wait count uniform
         const char* sk = smem + buf * (2 * KV_TILE_BYTES);
-        buf ^= 1;
+        buf = buf == RING - 1 ? 0 : buf + 1;
+        nbuf = nbuf == RING - 1 ? 0 : nbuf + 1;
         const char* sv = sk + KV_TILE_BYTES;
 
         if (!active) continue;  // wave-uniform: the wave still stages its share of every tile and meets every barrier
@@ -163,6 +175,7 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const void* __restrict__ q
     // ---- normalise and store: lane (q, hi) holds O[q][32 ds + 8 rg + 4 hi + 0..3] ----
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = active ? 1.0f / l_tot : 0.f;
+    if (!in_buf) return;
     Tt* op = (Tt*)out_ + (row0 + q_row) * C + h * 64 + 4 * hi;
 #pragma unroll
     for (int ds = 0; ds < 2; ++ds)
@@ -177,18 +190,28 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const void* __restrict__ q
 
 }  // namespace
 
+template <int NW, int RING>
+static int launch_attn(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, hipStream_t s) {
+    constexpr int QB = 32 * NW;
+    const int nqt = (Tp + QB - 1) / QB;
+    const int grid = nqt * H * B;
+    const size_t lds = RING * 2 * KV_TILE_BYTES;
+    const float scale_log2e = 0.125f * 1.44269504088896340736f;
+    if (dtype == MHMR_DT_F16)
+        hipLaunchKernelGGL((attn_kernel<MHMR_DT_F16, NW, RING>), dim3(grid), dim3(64 * NW), lds, s, qk, vt, out, T, Tp, C, H, nqt, scale_log2e);
+    else
+        hipLaunchKernelGGL((attn_kernel<MHMR_DT_BF16, NW, RING>), dim3(grid), dim3(64 * NW), lds, s, qk, vt, out, T, Tp, C, H, nqt, scale_log2e);
+    return 0;
+}
+
+// Measured at ViT-L 896 b32 (tools/kbench.py): <4,2> 852, <4,3> 832, <8,2> 855, <8,3> 855-860, <8,4> 854 TFLOP/s -- halving the
+// L2->LDS traffic (NW = 8) or deepening the ring changes nothing: the kernel is bound by the per-wave issue mix (16 MFMA, ~150 VALU
+// incl. 32 v_exp, 16 ds_read_b128 per tile), and only waves/SIMD moved it (3 -> 4: +2.8 %).  <4,2> is the shipped configuration.
 int mhmr_launch_attention(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype,
                           hipStream_t s) {
-    if (C != H * 64 || Tp % QB || T > Tp || T <= 0) return MHMR_ERR_BAD_SHAPE;
-    const int nqt = Tp / QB;
-    const int grid = nqt * H * B;
-    const size_t lds = 4 * KV_TILE_BYTES;   // 32 KiB -> 4 workgroups (16 waves) per CU at 114 VGPRs
-    const float scale_log2e = 0.125f * 1.44269504088896340736f;
+    if (C != H * 64 || Tp % 128 || T > Tp || T <= 0) return MHMR_ERR_BAD_SHAPE;
     prof_begin(PROF_ATTN, s);
-    if (dtype == MHMR_DT_F16)
-        hipLaunchKernelGGL((attn_kernel<MHMR_DT_F16>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, scale_log2e);
-    else
-        hipLaunchKernelGGL((attn_kernel<MHMR_DT_BF16>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, scale_log2e);
+    launch_attn<4, 2>(qk, vt, out, B, T, Tp, C, H, dtype, s);
     prof_end(PROF_ATTN, s, 4.0 * B * H * (double)T * T * 64);
     MHMR_CHECK_LAUNCH();
     return 0;
