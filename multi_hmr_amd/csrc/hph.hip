@@ -292,16 +292,21 @@ __global__ __launch_bounds__(64) void hph_self_attn_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------------------------
 // Cross-attention of the queries of image b over its N context tokens (CrossAttention.forward :185-205).
-// q: [P, inner]; kv: [B*N, 2*inner] (k | v) fp32.  One wave per (chunk of <= 8 queries, head): lane = slice*8 + qi,
-// slice s handles keys j = s (mod 8); the 8 partial (m, l, o) per query are merged with 3 xor-shuffle rounds.
+// q: [P, inner]; kv: [B*N, 2*inner] (k | v) fp32.  One workgroup of CA_WAVES waves per (chunk of <= 8 queries, head):
+// lane = slice*8 + qi, wave w's slice s handles keys j = s + 8 w (mod 8 CA_WAVES); the 8 partial (m, l, o) per query of a
+// wave are merged with 3 xor-shuffle rounds, the CA_WAVES wave results through LDS in wave order (deterministic).  The loop
+// is latency-bound (one 256-byte K|V row pair per lane-slice per trip): a single wave per (chunk, head) walked 512 trips at
+// N = 4096 (0.56 ms per layer); 8 waves walk 64 each.
 // chunks: (image b, first query, count) int triples built on the host from the per-image counts.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void hph_cross_attn_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+constexpr int CA_WAVES = 8;
+__global__ __launch_bounds__(64 * CA_WAVES) void hph_cross_attn_kernel(const float* __restrict__ q, const float* __restrict__ kv,
                                                             const int* __restrict__ chunks, float* __restrict__ out, int inner,
                                                             int N, float scale) {
     const int ch = blockIdx.x, h = blockIdx.y;
     const int b = chunks[3 * ch], q0 = chunks[3 * ch + 1], nq = chunks[3 * ch + 2];
-    const int lane = threadIdx.x, qi = lane & 7, sl = lane >> 3;
+    __shared__ float part[CA_WAVES][8][34];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, qi = lane & 7, sl = lane >> 3;
     const bool active = qi < nq;
     const float* qp = q + (size_t)(q0 + (active ? qi : 0)) * inner + h * 32;
     float qv[32], o[32];
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(64) void hph_cross_attn_kernel(const float* __restr
     float m = -INFINITY, l = 0.f;
     const int ld = 2 * inner;
     const float* kbase = kv + (size_t)b * N * ld + h * 32;
-    for (int j = sl; j < N; j += 8) {
+    for (int j = sl + 8 * wv; j < N; j += 8 * CA_WAVES) {
         const float* kp = kbase + (size_t)j * ld;
         const float* vp = kp + inner;
         float kk[32];
@@ -345,8 +350,30 @@ __global__ __launch_bounds__(64) void hph_cross_attn_kernel(const float* __restr
         for (int d = 0; d < 32; ++d) o[d] = o[d] * a1 + __shfl_xor(o[d], off) * a2;
         m = mn;
     }
-    if (active && sl == 0) {
-        const float inv = 1.0f / l;
+    // merge the waves: lanes 0..7 of every wave hold (m, l, o) of query qi over that wave's keys
+    if (sl == 0) {
+        part[wv][qi][32] = m;
+        part[wv][qi][33] = l;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) part[wv][qi][d] = o[d];
+    }
+    __syncthreads();
+    if (wv == 0 && active && sl == 0) {
+        float mt = part[0][qi][32];
+#pragma unroll
+        for (int w2 = 1; w2 < CA_WAVES; ++w2) mt = fmaxf(mt, part[w2][qi][32]);
+        float lt = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < CA_WAVES; ++w2) {
+            const float mw = part[w2][qi][32];
+            const float a = (mw == -INFINITY) ? 0.f : expf(mw - mt);
+            lt += part[w2][qi][33] * a;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) o[d] += part[w2][qi][d] * a;
+        }
+        const float inv = 1.0f / lt;
         float* op = out + (size_t)(q0 + qi) * inner + h * 32;
 #pragma unroll
         for (int d = 0; d < 32; ++d) op[d] = o[d] * inv;
@@ -517,7 +544,7 @@ int mhmr_launch_hph_self_attn(const float* qkv, const int* gstart, float* out, i
 int mhmr_launch_hph_cross_attn(const float* q, const float* kv, const int* chunks, int nchunks, float* out, int heads, int N,
                                hipStream_t s) {
     if (nchunks <= 0) return 0;
-    hipLaunchKernelGGL(hph_cross_attn_kernel, dim3(nchunks, heads), dim3(64), 0, s, q, kv, chunks, out, heads * 32, N,
+    hipLaunchKernelGGL(hph_cross_attn_kernel, dim3(nchunks, heads), dim3(64 * CA_WAVES), 0, s, q, kv, chunks, out, heads * 32, N,
                        0.17677669529663688110f);
     MHMR_CHECK_LAUNCH();
     return 0;

@@ -26,6 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = {
     "vits_224_train": dict(backbone="dinov2_vits14", img_size=224, depth_override=2, batch=3, persons=[3, 0, 2], seed=1),
     "vitl_224_train": dict(backbone="dinov2_vitl14", img_size=224, depth_override=None, batch=2, persons=[2, 1], seed=2),
+    "vitb_224_train": dict(backbone="dinov2_vitb14", img_size=224, depth_override=4, batch=2, persons=[1, 2], seed=4),
     "vits_448_infer": dict(backbone="dinov2_vits14", img_size=448, depth_override=2, batch=3, persons=None, seed=3,
                            nms_kernel_size=3, target_detections=5),
 }
@@ -62,7 +63,10 @@ def case_state_dict(cfg):
 def main():
     smplx_data = synthetic.make_smplx_data(seed=0)
     mean_params = synthetic.make_mean_params(seed=0)
+    only = sys.argv[1:]                               # optional: regenerate just the named cases
     for name, cfg in CASES.items():
+        if only and name not in only:
+            continue
         sd = case_state_dict(cfg)
         x, K, idx = case_inputs(cfg)
         with ref_shim.reference_modules(smplx_data, mean_params, cfg["depth_override"]) as ref:

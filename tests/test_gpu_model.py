@@ -39,7 +39,7 @@ def build(cfg, smplx_data, mean_params, precision, sd=None):
 
 
 @pytest.mark.parametrize("precision", ["f16", "bf16"])
-@pytest.mark.parametrize("name", ["vits_224_train", "vitl_224_train"])
+@pytest.mark.parametrize("name", ["vits_224_train", "vitb_224_train", "vitl_224_train"])
 def test_training_mode_matches_reference_golden(name, precision, smplx_data, mean_params):
     cfg = make_golden.CASES[name]
     gold = np.load(os.path.join(GOLD, name + ".npz"))
