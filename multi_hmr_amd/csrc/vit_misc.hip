@@ -49,14 +49,16 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// One wave per row; NP = C / 128 float2 per lane.  Two-pass (mean, then centred variance) in registers.
-template <int DT, int NP, bool FINAL>
+// One wave per row; a lane holds NP vectors of VEC floats (C = NP * 64 * VEC; VEC = 4 -> 16-byte loads / 8-byte stores whenever
+// C % 256 == 0, VEC = 2 for C = 384).  Two-pass (mean, then centred variance) in registers.
+template <int DT, int NP, int VEC, bool FINAL>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, const float* __restrict__ gw,
                                                         const float* __restrict__ gb, void* __restrict__ out16_, int ld16,
                                                         float* __restrict__ out32, int rows, int Np, int Tp, float eps) {
     typedef typename Op<DT>::T T;
-    typedef typename Op<DT>::V2 V2;
-    constexpr int C = NP * 128;
+    typedef float fv __attribute__((ext_vector_type(VEC)));
+    typedef T hv __attribute__((ext_vector_type(VEC)));
+    constexpr int C = NP * 64 * VEC;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -66,35 +68,38 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         in_row = (size_t)b * Tp + 1 + n;
     }
     const float* ip = in + in_row * C;
-    f32x2 v[NP];
+    fv v[NP];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        v[i] = *(const f32x2*)(ip + (i * 64 + lane) * 2);
-        s += v[i][0] + v[i][1];
+        v[i] = *(const fv*)(ip + (i * 64 + lane) * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s += v[i][e];
     }
     const float mean = wave_sum(s) * (1.0f / C);
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        v[i][0] -= mean;
-        v[i][1] -= mean;
-        q += v[i][0] * v[i][0] + v[i][1] * v[i][1];
-    }
+    for (int i = 0; i < NP; ++i)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            v[i][e] -= mean;
+            q += v[i][e] * v[i][e];
+        }
     const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + eps);
     T* o16 = (T*)out16_ + out_row * ld16;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int c = (i * 64 + lane) * 2;
-        const f32x2 w = *(const f32x2*)(gw + c), bb = *(const f32x2*)(gb + c);
-        f32x2 y;
-        y[0] = v[i][0] * rstd * w[0] + bb[0];
-        y[1] = v[i][1] * rstd * w[1] + bb[1];
-        V2 h;
-        h[0] = (T)y[0];
-        h[1] = (T)y[1];
-        *(V2*)(o16 + c) = h;
-        if constexpr (FINAL) *(f32x2*)(out32 + out_row * C + c) = y;
+        const int c = (i * 64 + lane) * VEC;
+        const fv w = *(const fv*)(gw + c), bb = *(const fv*)(gb + c);
+        fv y;
+        hv h;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            y[e] = v[i][e] * rstd * w[e] + bb[e];
+            h[e] = (T)y[e];
+        }
+        *(hv*)(o16 + c) = h;
+        if constexpr (FINAL) *(fv*)(out32 + out_row * C + c) = y;
     }
 }
 
@@ -102,15 +107,15 @@ template <int DT, bool FINAL>
 int launch_ln(const float* in, const float* w, const float* b, void* out16, int ld16, float* out32, int rows, int C,
               int Np, int Tp, float eps, hipStream_t s) {
     const int grid = (rows + 3) / 4;
-#define LN_CASE(NPV)                                                                                                     \
-    case NPV * 128:                                                                                                      \
-        hipLaunchKernelGGL((layernorm_kernel<DT, NPV, FINAL>), dim3(grid), dim3(256), 0, s, in, w, b, out16, ld16, out32, \
+#define LN_CASE(CV, NPV, VECV)                                                                                           \
+    case CV:                                                                                                             \
+        hipLaunchKernelGGL((layernorm_kernel<DT, NPV, VECV, FINAL>), dim3(grid), dim3(256), 0, s, in, w, b, out16, ld16, out32, \
                            rows, Np, Tp, eps);                                                                           \
         break;
     switch (C) {
-        LN_CASE(3)
-        LN_CASE(6)
-        LN_CASE(8)
+        LN_CASE(384, 3, 2)
+        LN_CASE(768, 3, 4)
+        LN_CASE(1024, 4, 4)
         default:
             return MHMR_ERR_BAD_SHAPE;
     }
