@@ -3,20 +3,27 @@
 //   workgroup = 8 waves (2 x 4) on one CU (1 block/CU, 2 waves per SIMD); LDS = 128 KiB DMA ring (2 K-tile buffers
 //   even/odd x 4 half-tile slots P0, P1, Q0, Q1; 128 rows x 64 k, 16 KiB each) + 32 KiB epilogue staging.  A wave owns
 //   64 P-rows in EACH P half and 32 Q-rows in EACH Q half, so its 128x64 output splits into 4 quadrants and every
-//   half-tile slot is read in exactly one phase by all waves:
+//   half-tile slot is read in exactly one phase by all waves.  One pair of K tiles (t in the even buffer e, t+1 in the odd
+//   buffer o) = 8 phases; the quadrant order is chosen so that the LDS reads alternate 8 / 4 per phase (a 12 / 4 / 8 / 0
+//   pattern made the reading group outlast the other group's 16 MFMAs) without any extra fragment registers:
 //
-//     phase   ds_read (slot -> regs)        MFMA (16 x v_mfma_f32_16x16x32)       LDS-DMA issued (2 x glds16 / thread)
-//     1 / 5   P0 -> PR (8), Q0 -> QA (4)    acc[0][0] += PR x QA                  Q1(odd,  t1) / Q1(even, t2)
-//     2 / 6   Q1 -> QB (4)                  acc[0][1] += PR x QB                  P1(odd,  t1) / P1(even, t2)
-//     3 / 7   P1 -> PR (8)                  acc[1][1] += PR x QB                  Q0(even, t2) / Q0(odd,  t3)
-//     4 / 8   --                            acc[1][0] += PR x QA                  P0(even, t2) / P0(odd,  t3)
+//     phase   ds_read (slot -> regs)   MFMA (16 x v_mfma_f32_16x16x32)   LDS-DMA issued (2 x glds16 / thread)
+//     1       P0e -> PR (8)            acc[0][0] += PR x QA              P1o <- tile t+1
+//     2       Q1e -> QB (4)            acc[0][1] += PR x QB              Q0e <- tile t+2
+//     3       P1e -> PR (8)            acc[1][1] += PR x QB              P0e <- tile t+2
+//     4       Q1o -> QB (4)            acc[1][0] += PR x QA              Q1e <- tile t+2
+//     5       P0o -> PR (8)            acc[0][1] += PR x QB              P1e <- tile t+2
+//     6       Q0o -> QA (4)            acc[0][0] += PR x QA              Q1o <- tile t+3
+//     7       P1o -> PR (8)            acc[1][0] += PR x QA              P0o <- tile t+3
+//     8       Q0e(t+2) -> QA (4)       acc[1][1] += PR x QB              Q0o <- tile t+3
 //
-//   Every phase is  [ds_reads ; DMA issue ; s_waitcnt vmcnt(8)] s_barrier [MFMAs] s_barrier.  The two wave groups
+//   Every phase is  [ds_reads ; DMA issue ; s_waitcnt vmcnt(10)] s_barrier [MFMAs] s_barrier.  The two wave groups
 //   (wp = 0 / 1, one wave of each per SIMD) run ONE barrier apart, so while one group's 16 MFMAs (8 independent
 //   accumulators: no dependent-issue stalls with only one computing wave per SIMD) occupy the SIMD's matrix pipe the
-//   other group issues its LDS reads and DMA.  vmcnt(8) after each issue = "the half-tile issued 4 phases ago has
-//   landed": every slot is waited for one phase before it is first read (RAW = wait + barrier) and re-filled >= 2
-//   phases after its last read (WAR); the DMA queue is never drained inside the K loop.
+//   other group issues its LDS reads and DMA.  Each phase re-fills the slot that was read TWO phases earlier (WAR: two
+//   barriers and the readers' lgkmcnt wait lie between) with the data that slot serves six phases later; vmcnt(10) after
+//   each issue = "everything but the five newest half-tiles has landed" = the slot the NEXT phase reads (RAW = wait +
+//   barrier).  The DMA queue is never drained inside the K loop.
 //
 //   Persistent: a block walks its output tiles; the K-tile indices t2, t3 that run past the end of one tile are the
 //   first K tiles of the NEXT tile, so the ring stays full across tile boundaries and the next tile's operands stream
@@ -59,18 +66,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     const int srow = tid >> 3;                                  // 0..63
     const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
     const int nt = g.K / 64;
-    auto tile_src = [&](int tix, const T*& ps, const T*& qs, int& p0, int& q0) {
+    // operand positions are 32-bit ELEMENT offsets from the uniform bases Pm / Qm (eligibility: M*K, N*K < 2^31): half the
+    // registers of per-lane 64-bit pointers
+    auto tile_src = [&](int tix, uint32_t& ps, uint32_t& qs, int& p0, int& q0) {
         const int tn = tix % nbn, tm = tix / nbn;
         p0 = ROWMAJOR ? tn * 256 : tm * 256;
         q0 = ROWMAJOR ? tm * 256 : tn * 256;
-        ps = Pm + (size_t)(p0 + srow) * ldp + schunk * 8;
-        qs = Qm + (size_t)(q0 + srow) * ldq + schunk * 8;
+        ps = (uint32_t)(p0 + srow) * (uint32_t)ldp + (uint32_t)(schunk * 8);
+        qs = (uint32_t)(q0 + srow) * (uint32_t)ldq + (uint32_t)(schunk * 8);
     };
-    auto dma = [&](const T* src, int ld, int half, int kt, int lds_off) {
-        const T* s = src + (size_t)(128 * half) * ld + kt * 64;
+    auto dma = [&](const T* base, uint32_t src, int ld, int half, int kt, int lds_off) {
+        const uint32_t o = src + (uint32_t)(128 * half) * (uint32_t)ld + (uint32_t)(kt * 64);
         char* d = smem + lds_off + w * 1024;
-        glds16(s, d);
-        glds16(s + (size_t)64 * ld, d + 8192);
+        glds16(base + o, d);
+        glds16(base + (o + 64u * (uint32_t)ld), d + 8192);
     };
 
     // ---- fragment read addressing (16-row sub-tiles; chunk = 4*ks + g4 within the 128-byte row) ----
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
 #define MHMR_SYNC()                          \
     __builtin_amdgcn_s_barrier();            \
     __builtin_amdgcn_sched_barrier(0)
-#define MHMR_WAIT_DMA() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define MHMR_WAIT_DMA() asm volatile("s_waitcnt vmcnt(10)" ::: "memory")
 
     // The bias is the accumulators' initial value: the epilogue then has no bias loads at all (a global load there is followed by
     // its s_waitcnt vmcnt(0), which also waits for every store already issued -- 16 serialized HBM round trips per tile).  The
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         }
     };
 
-    const T *p_src, *q_src, *p_nxt, *q_nxt;
+    uint32_t p_src, q_src, p_nxt, q_nxt;
     int p0, q0, p0n, q0n;
     if (first >= ntiles) return;             // (never with the launcher's grid; keeps barrier counts trivially equal)
     if (g.stagger_ticks > 0) {       // CU quarters start 0/1/2/3 x stagger_ticks late so their epilogue bursts interleave (gemm.hip)
@@ -134,19 +143,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     }
     tile_src(first, p_src, q_src, p0, q0);
 
-    // ---- prologue (first tile only): K tile 0 -> even buffer (all four halves), K tile 1 -> odd buffer (Q0, P0) ----
-    dma(q_src, ldq, 0, 0, SLOT_Q0);
-    dma(p_src, ldp, 0, 0, SLOT_P0);
-    dma(q_src, ldq, 1, 0, SLOT_Q1);
-    dma(p_src, ldp, 1, 0, SLOT_P1);
-    dma(q_src, ldq, 0, 1, BUF + SLOT_Q0);
-    dma(p_src, ldp, 0, 1, BUF + SLOT_P0);
+    // ---- prologue (first tile only): K tile 0 -> even buffer (all four halves), K tile 1 -> odd buffer (Q1, P0, Q0; P1 follows
+    //      in phase 1 like in every later pair) ----
+    dma(Qm, q_src, ldq, 0, 0, SLOT_Q0);
+    dma(Pm, p_src, ldp, 0, 0, SLOT_P0);
+    dma(Qm, q_src, ldq, 1, 0, SLOT_Q1);
+    dma(Pm, p_src, ldp, 1, 0, SLOT_P1);
+    dma(Qm, q_src, ldq, 1, 1, BUF + SLOT_Q1);
+    dma(Pm, p_src, ldp, 0, 1, BUF + SLOT_P0);
+    dma(Qm, q_src, ldq, 0, 1, BUF + SLOT_Q0);
 #pragma unroll
     for (int a = 0; a < 8; ++a) acc_init(a >> 2, (a >> 1) & 1, a & 1, p0, q0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MHMR_SYNC();
 
     for (int tix = first; tix < ntiles; tix += G) {
+        // Q0 of this tile's first K tile (landed and published by the previous pair's phase-8 wait + barrier, or by the prologue)
+        rdQ(QA, 0, SLOT_Q0);
         if (wp == 1) { MHMR_SYNC(); }       // stagger: during the K loop group 1 runs one barrier behind group 0
         const bool has_next = tix + G < ntiles;
         if (has_next) tile_src(tix + G, p_nxt, q_nxt, p0n, q0n);
@@ -154,39 +167,42 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         for (int t = 0; t < nt; t += 2) {
             // K-tile indices past the end of this tile are the first K tiles of the next one
             const bool wrap = t + 2 >= nt;
-            const T* p2 = wrap ? p_nxt : p_src;
-            const T* q2 = wrap ? q_nxt : q_src;
+            const uint32_t p2 = wrap ? p_nxt : p_src;
+            const uint32_t q2 = wrap ? q_nxt : q_src;
             const int t1 = t + 1, t2 = wrap ? (has_next ? 0 : nt - 1) : t + 2, t3 = wrap ? (has_next ? 1 : nt - 1) : t + 3;
             // phase 1
-            rdP(0, SLOT_P0); rdQ(QA, 0, SLOT_Q0);
-            dma(q_src, ldq, 1, t1, BUF + SLOT_Q1); MHMR_WAIT_DMA();
+            rdP(0, SLOT_P0);
+            dma(Pm, p_src, ldp, 1, t1, BUF + SLOT_P1); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[0][0], QA); MHMR_SYNC();
             // phase 2
             rdQ(QB, 0, SLOT_Q1);
-            dma(p_src, ldp, 1, t1, BUF + SLOT_P1); MHMR_WAIT_DMA();
+            dma(Qm, q2, ldq, 0, t2, SLOT_Q0); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[0][1], QB); MHMR_SYNC();
             // phase 3
             rdP(0, SLOT_P1);
-            dma(q2, ldq, 0, t2, SLOT_Q0); MHMR_WAIT_DMA();
+            dma(Pm, p2, ldp, 0, t2, SLOT_P0); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[1][1], QB); MHMR_SYNC();
             // phase 4
-            dma(p2, ldp, 0, t2, SLOT_P0); MHMR_WAIT_DMA();
+            rdQ(QB, 1, SLOT_Q1);
+            dma(Qm, q2, ldq, 1, t2, SLOT_Q1); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[1][0], QA); MHMR_SYNC();
             // phase 5
-            rdP(1, SLOT_P0); rdQ(QA, 1, SLOT_Q0);
-            dma(q2, ldq, 1, t2, SLOT_Q1); MHMR_WAIT_DMA();
-            MHMR_SYNC(); mma(acc[0][0], QA); MHMR_SYNC();
-            // phase 6
-            rdQ(QB, 1, SLOT_Q1);
-            dma(p2, ldp, 1, t2, SLOT_P1); MHMR_WAIT_DMA();
+            rdP(1, SLOT_P0);
+            dma(Pm, p2, ldp, 1, t2, SLOT_P1); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[0][1], QB); MHMR_SYNC();
+            // phase 6
+            rdQ(QA, 1, SLOT_Q0);
+            dma(Qm, q2, ldq, 1, t3, BUF + SLOT_Q1); MHMR_WAIT_DMA();
+            MHMR_SYNC(); mma(acc[0][0], QA); MHMR_SYNC();
             // phase 7
             rdP(1, SLOT_P1);
-            dma(q2, ldq, 0, t3, BUF + SLOT_Q0); MHMR_WAIT_DMA();
-            MHMR_SYNC(); mma(acc[1][1], QB); MHMR_SYNC();
-            // phase 8
-            dma(p2, ldp, 0, t3, BUF + SLOT_P0); MHMR_WAIT_DMA();
+            dma(Pm, p2, ldp, 0, t3, BUF + SLOT_P0); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[1][0], QA); MHMR_SYNC();
+            // phase 8 (the next pair's Q0; at the end of a tile it is read after the epilogue instead, so that QA's registers are
+            // free for the epilogue)
+            if (!wrap) rdQ(QA, 0, SLOT_Q0);
+            dma(Qm, q2, ldq, 0, t3, BUF + SLOT_Q0); MHMR_WAIT_DMA();
+            MHMR_SYNC(); mma(acc[1][1], QB); MHMR_SYNC();
         }
 
         if (wp == 0) { MHMR_SYNC(); }       // re-align: both groups run the memory-bound epilogue together
@@ -358,6 +374,7 @@ int launch256_dt(const GemmArgs& g, hipStream_t s) {
 
 bool mhmr_gemm256_eligible(const GemmArgs& g) {
     if (g.epi == EPI_RESID && (uint64_t)g.M * (uint64_t)g.ldo * 4u >= (1ull << 32)) return false;   // 32-bit residual offsets
+    if ((uint64_t)g.M * (uint64_t)g.lda >= (1ull << 31) || (uint64_t)g.N * (uint64_t)g.ldw >= (1ull << 31)) return false;   // 32-bit operand offsets
     return g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && (g.epi != EPI_VT || g.Tp % 64 == 0);
 }
 
