@@ -49,10 +49,10 @@ def lbs_bytes(P, nb=10):
 
 def pmc_traffic():
     """HBM/fabric bytes per GEMM launch (average over the ViT-L 896 b32 launches) from the committed rocprofv3 PMC passes
-    (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc runs, tools/pmc_traffic.py -> profiles/r01_pmc_traffic.json); counters
+    (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc runs, tools/pmc_traffic.py -> profiles/r01_v6_pmc.json); counters
     cannot be read from inside the timed process, so this is null when the summary is absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_v6_pmc.json")) as f:
             return json.load(f).get("_gemm_avg_bytes_per_launch")
     except (OSError, ValueError):
         return None
