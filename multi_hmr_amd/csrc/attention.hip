@@ -19,6 +19,12 @@
 
 namespace {
 
+// max over the lane pair {l, l ^ 32} on the VALU (v_permlane32_swap): a ds_bpermute would queue behind the fragment reads in the LDS
+__device__ __forceinline__ float max_lane32(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 constexpr int KB = 64;
 constexpr int KV_TILE_BYTES = KB * 64 * 2;  // 8 KiB
 
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(const vo
         for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[0][r]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[1][r]);
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        mt = max_lane32(mt);
         const float m_new = fmaxf(m_run, mt * scale_log2e);
         if (!__all(m_new == m_run)) {
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -188,6 +194,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(const vo
         }
 }
 
+
 }  // namespace
 
 template <int NW, int RING>
@@ -207,6 +214,11 @@ static int launch_attn(const void* qk, const void* vt, void* out, int B, int T, 
 // Measured at ViT-L 896 b32 (tools/kbench.py): <4,2> 852, <4,3> 832, <8,2> 855, <8,3> 855-860, <8,4> 854 TFLOP/s -- halving the
 // L2->LDS traffic (NW = 8) or deepening the ring changes nothing: the kernel is bound by the per-wave issue mix (16 MFMA, ~150 VALU
 // incl. 32 v_exp, 16 ds_read_b128 per tile), and only waves/SIMD moved it (3 -> 4: +2.8 %).  <4,2> is the shipped configuration.
+// Role-structured variants were built, passed the parity and determinism tests, and lost: next tile's scores issued in the same
+// basic block as this tile's exps (two score tiles in registers, 3 waves/SIMD) 784; 8-wave two-group ping-pong (VALU phase /
+// 16-MFMA phase, fragments pre-read into registers) 640-740; 12-wave three-group rotation (one matrix wave + two VALU waves per
+// SIMD at any time, 4-slot ring) 795-822 TFLOP/s.  A lone wave issues VALU at ~5.5 cycles per instruction (tools/ubench), so the
+// softmax of one tile is 1100+ cycles beside 512 matrix-pipe cycles; four unsynchronised waves per SIMD hide that best.
 int mhmr_launch_attention(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype,
                           hipStream_t s) {
     if (C != H * 64 || Tp % 128 || T > Tp || T <= 0) return MHMR_ERR_BAD_SHAPE;
