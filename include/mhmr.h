@@ -214,6 +214,25 @@ int mhmr_lbs_forward(const mhmr_lbs_consts* c, const float* rotvec, const float*
                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Anny variant read-outs; the backbone, the detection head and the decoder stack reuse
+ * mhmr_vit_forward / mhmr_detect_* / mhmr_xattn_layers_forward.
+ *   mhmr_anny_camera: multi_hmr_anny/encoder.py:47-56 -- fov = fov_max * sigmoid(logit), focal = (S/2) / tan(fov/2),
+ *                     K [B][3][3] with the principal point at S/2.
+ *   mhmr_anny_decode: multi_hmr_anny/multi_hmr.py:144-177 -- per person: loc, dist = focal / clamp(exp(d), 1e-5),
+ *                     transl = K^-1 [loc,1] dist (utils/camera.py:30-48), J 6D rotations (rows of (3,2)) ->
+ *                     roma.special_gramschmidt -> identity where useful[j] == 0 -> roma.rotmat_to_rotvec,
+ *                     shape = sigmoid(shape_logit).  The body model (anny package) is outside this library.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* encoder.py:57-58: logits = hid16 . w2 + b2, scores = sigmoid(logits) (no clamp); hid16 as for mhmr_detect_scores. */
+int mhmr_anny_scores(const void* hid16, int ld, const float* w2, const float* b2, float* scores, float* logits, int rows,
+                     int C, int dtype, void* stream);
+int mhmr_anny_camera(const float* fov_logit, int B, int img_size, float fov_max, float* fov, float* K, void* stream);
+int mhmr_anny_decode(const float* rot6d, const float* useful, int J, const float* shape_logit, int nb,
+                     const float* dist_logit, const float* offset, const int* det_b, const int* det_y, const int* det_x,
+                     const float* K, int patch, int P, float* rotmat, float* rotvec, float* shape, float* loc, float* dist,
+                     float* transl, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Input preprocessing, the step before Model.forward:
  *   demo.py:27-51 open_image  = PIL ImageOps.contain(img, (S,S)) [bicubic, aspect kept] + ImageOps.pad(.., (S,S))
  *                               [centred, black] + utils/image.py:12-24 normalize_rgb.

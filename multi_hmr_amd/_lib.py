@@ -12,7 +12,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmhmr.so")
-SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "vit_misc.hip", "hph.hip", "lbs.hip", "preprocess.hip", "evalm.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "vit_misc.hip", "hph.hip", "lbs.hip", "preprocess.hip", "evalm.hip", "anny.hip", "capi.hip"]
 HEADERS = ["mhmr_common.h", "mhmr_internal.h", os.path.join("..", "..", "include", "mhmr.h")]
 
 DT_BF16, DT_F16 = 0, 1
@@ -90,6 +90,9 @@ _SIGS = {
     "mhmr_lbs_forward": ([C.POINTER(LbsConsts)] + [_vp] * 7 + [_i] + [_vp] * 8 + [_vp], _i),
     "mhmr_preprocess_u8": ([_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i] + [_i] * 7 + [_vp, _vp, _vp, _vp], _i),
     "mhmr_eval_mesh_errors": ([_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp], _i),
+    "mhmr_anny_scores": ([_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
+    "mhmr_anny_camera": ([_vp, _i, _i, _f, _vp, _vp, _vp], _i),
+    "mhmr_anny_decode": ([_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i] + [_vp] * 6 + [_vp], _i),
     "mhmr_prof_enable": ([_i], _i),
     "mhmr_prof_collect": ([C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)], _i),
 }

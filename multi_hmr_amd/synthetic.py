@@ -254,6 +254,91 @@ def make_state_dict(backbone: str = "dinov2_vitl14", img_size: int = 896, xat_de
     return sd
 
 
+ANNY_NUM_JOINTS = 163
+#: multi_hmr_anny/multi_hmr.py:78-88 (which of the 163 bone rotations are predicted; the others are forced to identity)
+ANNY_USEFUL_ROTMAT = ([1.] * 7 + [0.] * 14 + [1.] * 6 + [0.] * 14 + [1.] * 4 + [0.] * 2 + [1.] * 58 + [0.] * 58)
+
+
+def anny_sincos_pos_embed(embed_dim: int, grid_size: int) -> np.ndarray:
+    """multi_hmr_anny/pos_embed.py:12-61 (2D sine-cosine embedding, w goes first, no cls token): [grid*grid, embed_dim] float64.
+    First half of the channels encodes the x (column) index, second half the y (row) index; each half = [sin | cos] over
+    embed_dim/4 frequencies 1 / 10000^(i / (embed_dim/4))."""
+    assert embed_dim % 4 == 0
+    gw, gh = np.meshgrid(np.arange(grid_size, dtype=np.float32), np.arange(grid_size, dtype=np.float32))
+
+    def one(pos):
+        half = embed_dim // 2
+        omega = np.arange(half // 2, dtype=float)
+        omega /= half / 2.0
+        omega = 1.0 / 10000 ** omega
+        out = np.einsum("m,d->md", pos.reshape(-1), omega)
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+    return np.concatenate([one(gw), one(gh)], axis=1)
+
+
+def anny_init_body_pose() -> torch.Tensor:
+    """multi_hmr_anny/multi_hmr.py:90-96: root = the first two columns of Rx(pi/2), the other 162 bones = those of I; [1, 978]."""
+    c, s_ = math.cos(math.pi / 2), math.sin(math.pi / 2)
+    Rx = torch.tensor([[1.0, 0.0, 0.0], [0.0, c, -s_], [0.0, s_, c]])
+    root = Rx[:, :2].reshape(1, -1)
+    body = torch.eye(3).reshape(1, 3, 3).repeat(ANNY_NUM_JOINTS - 1, 1, 1)[:, :, :2].flatten(1).reshape(1, -1)
+    return torch.cat([root, body], -1)
+
+
+def make_state_dict_anny(backbone: str = "dinov2_vits14", img_size: int = 224, xat_dim: int = 512, xat_depth: int = 8,
+                         xat_heads: int = 16, xat_mlp_dim: int = 2048, num_betas: int = 11, seed: int = 0,
+                         depth_override: int | None = None) -> dict:
+    """Seeded random state_dict with the key names of ``multi_hmr_anny.multi_hmr.Multi_HMR`` (encoder.backbone.* = the hub
+    DINOv2, encoder.mlp_det / mlp_fov_unique, dec_to_token, decoder.transformer.layers.*, mlp_offset / mlp_pose / mlp_shape /
+    mlp_dist, buffers dec_pos_emb / init_body_pose / encoder.fov_max, parameters eye / useful_rotmat).  The body model's own
+    tensors (``anny`` package) are not part of it."""
+    assert len(ANNY_USEFUL_ROTMAT) == ANNY_NUM_JOINTS
+    base = make_state_dict(backbone, img_size, seed=seed, depth_override=depth_override)
+    sd = {"encoder.backbone." + k[len("backbone.encoder."):]: v for k, v in base.items() if k.startswith("backbone.encoder.")}
+    C = VIT_CFG[backbone]["embed_dim"]
+    g = torch.Generator().manual_seed(seed + 977)
+
+    def lin(name, out_f, in_f, std=None):
+        s = std if std is not None else 1.0 / math.sqrt(in_f)
+        sd[name + ".weight"] = s * torch.empty(out_f, in_f).normal_(0, 1, generator=g)
+        sd[name + ".bias"] = 0.02 * torch.empty(out_f).normal_(0, 1, generator=g)
+
+    lin("encoder.mlp_det.0", C, C)
+    lin("encoder.mlp_det.2", 1, C)
+    lin("encoder.mlp_fov_unique.0", C, C)
+    lin("encoder.mlp_fov_unique.2", 1, C, std=0.5 / math.sqrt(C))
+    sd["encoder.fov_max"] = torch.tensor([math.pi])
+    lin("dec_to_token", xat_dim, C)
+    inner = 32 * xat_heads
+    for l in range(xat_depth):
+        b = f"decoder.transformer.layers.{l}."
+        for k in range(3):
+            sd[f"{b}{k}.norm.weight"] = 1.0 + 0.1 * torch.empty(xat_dim).normal_(0, 1, generator=g)
+            sd[f"{b}{k}.norm.bias"] = 0.05 * torch.empty(xat_dim).normal_(0, 1, generator=g)
+        sd[b + "0.fn.to_qkv.weight"] = xat_dim ** -0.5 * torch.empty(3 * inner, xat_dim).normal_(0, 1, generator=g)
+        lin(b + "0.fn.to_out.0", xat_dim, inner)
+        sd[b + "1.fn.to_kv.weight"] = xat_dim ** -0.5 * torch.empty(2 * inner, xat_dim).normal_(0, 1, generator=g)
+        sd[b + "1.fn.to_q.weight"] = xat_dim ** -0.5 * torch.empty(inner, xat_dim).normal_(0, 1, generator=g)
+        lin(b + "1.fn.to_out.0", xat_dim, inner)
+        lin(b + "2.fn.net.0", xat_mlp_dim, xat_dim)
+        lin(b + "2.fn.net.3", xat_dim, xat_mlp_dim)
+    J = ANNY_NUM_JOINTS
+    lin("mlp_offset.0", xat_dim, xat_dim)
+    lin("mlp_offset.2", 2, xat_dim, std=0.2 / math.sqrt(xat_dim))
+    lin("mlp_pose.0", xat_dim, xat_dim + 6 * J)
+    lin("mlp_pose.2", 6 * J, xat_dim, std=0.15 / math.sqrt(xat_dim))
+    lin("mlp_shape.0", xat_dim, xat_dim)
+    lin("mlp_shape.2", num_betas, xat_dim)
+    lin("mlp_dist.0", xat_dim, xat_dim)
+    lin("mlp_dist.2", 1, xat_dim, std=0.3 / math.sqrt(xat_dim))
+    sd["mlp_dist.2.bias"] = torch.tensor([5.0])       # exp(5) ~ 148: distances of a few metres at f ~ 200-800 px
+    sd["dec_pos_emb"] = torch.from_numpy(anny_sincos_pos_embed(xat_dim, img_size // 14)).float()
+    sd["init_body_pose"] = anny_init_body_pose()
+    sd["eye"] = torch.eye(3).unsqueeze(0)
+    sd["useful_rotmat"] = torch.tensor(ANNY_USEFUL_ROTMAT).unsqueeze(0)
+    return sd
+
+
 def get_camera_K(img_size: int, batch: int = 1, fov: float = 60.0) -> torch.Tensor:
     """K of reference demo.py:53-68 (fx=fy=S/(2 tan(fov/2)), principal point S//2), repeated."""
     K = torch.eye(3)
