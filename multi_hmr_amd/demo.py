@@ -21,10 +21,15 @@ def load_model(model_name, device=torch.device("cuda"), **model_kwargs):
         raise FileNotFoundError(f"{ckpt_path} not found")
     ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
     kwargs = dict(vars(ckpt["args"]))
-    kwargs["type"] = ckpt["args"].train_return_type
-    kwargs["img_size"] = ckpt["args"].img_size[0]
-    kwargs.update(model_kwargs)
-    model = Model(**kwargs).to(device)
+    if "anny" in ckpt_path:                      # demo.py:94-95: the Anny checkpoints build multi_hmr_anny.multi_hmr.Multi_HMR
+        from .anny_model import Multi_HMR as ModelAnny
+        kwargs.update(model_kwargs)
+        model = ModelAnny(**kwargs).to(device)
+    else:
+        kwargs["type"] = ckpt["args"].train_return_type
+        kwargs["img_size"] = ckpt["args"].img_size[0]
+        kwargs.update(model_kwargs)
+        model = Model(**kwargs).to(device)
     model.load_state_dict(ckpt["model_state_dict"], strict=False)
     return model
 

@@ -66,3 +66,18 @@ def test_loaded_checkpoint_matches_in_memory_model_and_oracle(asset_tree):
     for k in ("v3d", "j3d", "transl", "rotmat"):            # 6-influence skinning through the file path, vs the CPU oracle
         rel = float((a[k].cpu() - ref[k]).norm() / ref[k].norm())
         assert rel < 1e-3, (k, rel)
+
+
+def test_load_model_dispatches_anny_checkpoints(tmp_path, monkeypatch):
+    """demo.py:94-95: a checkpoint whose path contains 'anny' builds the Anny model from the saved argument namespace."""
+    from multi_hmr_amd.anny_model import Multi_HMR as ModelAnny
+    os.makedirs(tmp_path / "models" / "multiHMR")
+    sd = synthetic.make_state_dict_anny("dinov2_vits14", 224, xat_depth=2, seed=1, depth_override=2)
+    args = argparse.Namespace(backbone="dinov2_vits14", img_size=224, xat_depth=2, simple_depth_encoding=1, num_betas=11, backbone_depth=2,
+                              train_data="BEDLAM", batch_size=4, learning_rate=1e-5)
+    torch.save({"args": args, "model_state_dict": sd}, tmp_path / "models" / "multiHMR" / "multiHMR_anny_synth.pt")
+    monkeypatch.chdir(tmp_path)
+    m = load_model("multiHMR_anny_synth", device=torch.device("cpu"))
+    assert isinstance(m, ModelAnny) and m.img_size == 224 and m.decoder.depth == 2
+    got = m.state_dict()
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd if k != "init_body_pose")
