@@ -67,3 +67,21 @@ def test_lbs_160_persons_linear_in_betas_at_zero_pose(smplx_data):
     lhs, rhs = v12 - v0, (v1 - v0) + (v2 - v0)
     assert float((lhs - rhs).abs().max()) < 5e-6
     assert float((v1 - v0).abs().max()) > 1e-3
+
+
+def test_vitl_1288_twenty_persons(smplx_data, mean_params):
+    """BASELINE config 5 shape (1288x1288, 20 persons per image) on one image: G = 92, T = 8465 tokens -- beyond the 64x64 grid the
+    camera embedding was sized for in most checkpoints; finite outputs, right shapes, bit-exact repeat."""
+    m = Model(backbone="dinov2_vitl14", img_size=1288, smplx_data=smplx_data, mean_params=mean_params, precision="bf16", backbone_depth=2)
+    m.load_state_dict(synthetic.make_state_dict("dinov2_vitl14", 1288, seed=0, mean_params=mean_params, depth_override=2), strict=True)
+    m = m.to("cuda:0").eval()
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    x = torch.randn(1, 3, 1288, 1288, generator=g, device="cuda:0")
+    K = synthetic.get_camera_K(1288, 1).cuda()
+    idx = tuple(t.cuda() for t in synthetic.make_pinned_idx(1, 92, 20, seed=3))
+    a = m(x, idx=idx, K=K, is_training=True)
+    b = m(x, idx=idx, K=K, is_training=True)
+    assert a["v3d"].shape == (20, 10475, 3) and a["scores"].shape == (1, 92, 92, 1)
+    for k in ("scores", "v3d", "j2d", "transl", "rotmat"):
+        assert torch.isfinite(a[k]).all(), k
+        assert torch.equal(a[k], b[k]), k
