@@ -119,6 +119,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(const vo
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+        __builtin_amdgcn_s_setprio(1);   // matrix sections outrank the other waves' VALU work at the issue arbiter (+1-2 %)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             V8 kf[2];
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(const vo
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) s[sub] = Op<DT>::mfma32(kf[sub], qf[ks], s[sub]);
         }
+        __builtin_amdgcn_s_setprio(0);
         // ---- mask keys >= T (only the last tile can contain them) ----
         if (j * KB + KB > T) {
 #pragma unroll
@@ -164,6 +166,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(const vo
         l_run += psum;
 
         // ---- O^T += V^T . P^T ----
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             V8 pf;
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(const vo
                 o[ds] = Op<DT>::mfma32(vf, pf, o[ds]);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
