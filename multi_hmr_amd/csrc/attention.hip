@@ -106,13 +106,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(const vo
         static_assert(OPS * (RING - 2) <= 8, "extend the counted waits");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        stage(j + RING - 1 < ntile ? j + RING - 1 : ntile - 1, nbuf);   // tail: harmless re-load, keeps the wait count uniform
         const char* sk = smem + buf * (2 * KV_TILE_BYTES);
+        const char* sv = sk + KV_TILE_BYTES;
+        const int nbuf_now = nbuf;
         buf = buf == RING - 1 ? 0 : buf + 1;
         nbuf = nbuf == RING - 1 ? 0 : nbuf + 1;
-        const char* sv = sk + KV_TILE_BYTES;
-
-        if (!active) continue;  // wave-uniform: the wave still stages its share of every tile and meets every barrier
+        if (!active) {          // wave-uniform: the wave still stages its share of every tile and meets every barrier
+            stage(j + RING - 1 < ntile ? j + RING - 1 : ntile - 1, nbuf_now);
+            continue;
+        }
         // ---- S^T = K . Q^T ----
         f32x16 s[2];   // the two key halves alternate in issue order: back-to-back MFMAs never share an accumulator
 #pragma unroll
@@ -129,6 +131,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(const vo
             for (int sub = 0; sub < 2; ++sub) s[sub] = Op<DT>::mfma32(kf[sub], qf[ks], s[sub]);
         }
         __builtin_amdgcn_s_setprio(0);
+        // the next tile's DMA is issued behind the score MFMAs (its address arithmetic no longer delays the first fragment reads);
+        // tail: harmless re-load, keeps the wait count uniform
+        stage(j + RING - 1 < ntile ? j + RING - 1 : ntile - 1, nbuf_now);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- mask keys >= T (only the last tile can contain them) ----
         if (j * KB + KB > T) {
 #pragma unroll
