@@ -61,7 +61,7 @@ def allgather_persons(batched: dict, image_offset: int = 0, image_index: torch.T
     if image_index is None:
         image_index = torch.zeros(rec.shape[0], dtype=torch.long, device=dev)
     rec = torch.cat([rec, (image_index.to(dev).float() + image_offset).unsqueeze(1)], dim=1)
-    if world == 1:
+    if not dist.is_initialized():          # single process without a process group; an initialised group of one still runs the collectives
         return unpack_records(rec[:, :-1], fields), rec[:, -1].long()
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
     mine = torch.tensor([rec.shape[0]], dtype=torch.int64, device=dev)
