@@ -108,12 +108,20 @@ def main():
     K = synthetic.get_camera_K(S, B).to(dev)
     idx = tuple(t.to(dev) for t in synthetic.make_pinned_idx(B, S // 14, q, seed=rank))
 
+    pending = []          # N > 1: the collation of step i travels over xGMI while step i + 1 computes (waited one step later)
+
     def step():
         out = model(x, idx=idx, K=K, is_training=True)
         if world > 1:
             out["scores"] = out["scores"][idx[0], idx[1], idx[2], 0]      # per-person score slot of the record
-            collate.allgather_persons(out, image_offset=rank * B, image_index=idx[0])
+            pending.append(collate.allgather_persons_async(out, capacity=B * q, image_offset=rank * B, image_index=idx[0]))
+            if len(pending) > 1:
+                pending.pop(0).wait()
         return out
+
+    def drain():
+        while pending:
+            pending.pop(0).wait()
 
     def barrier():
         if world > 1:
@@ -122,11 +130,13 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     barrier()
     prof_window(0)                       # hipEvent brackets around every GEMM launch of the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()               # every step's persons are collated on every rank inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     n_gemm, ms_gemm, _ = prof_collect()

@@ -77,6 +77,44 @@ def allgather_persons(batched: dict, image_offset: int = 0, image_index: torch.T
     return unpack_records(allrec[:, :-1], fields), allrec[:, -1].long()
 
 
+class PendingGather:
+    """Handle of ``allgather_persons_async``: ``wait()`` -> (dict of [P_total, ...] tensors in global order, image_index [P_total])."""
+
+    def __init__(self, works, gathered, counts, capacity, world, fields):
+        self._works, self._gathered, self._counts, self._cap, self._world, self._fields = works, gathered, counts, capacity, world, fields
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        cl = self._counts.tolist()
+        parts = [self._gathered[r * self._cap: r * self._cap + cl[r]] for r in range(self._world)]
+        allrec = torch.cat(parts, dim=0)
+        return unpack_records(allrec[:, :-1], self._fields), allrec[:, -1].long()
+
+
+def allgather_persons_async(batched: dict, capacity: int, image_offset: int = 0, image_index: torch.Tensor | None = None, group=None,
+                            fields=RECORD) -> PendingGather:
+    """The same exchange without a host round trip in front of it: every rank pads its records to ``capacity`` persons (an upper
+    bound the caller knows, e.g. images x max detections), and both collectives (counts, records) are enqueued with
+    ``async_op=True`` so that RCCL moves this step's persons over xGMI while the next step's kernels run; the caller ``wait()``s
+    later.  Needs an initialised process group."""
+    world = dist.get_world_size(group)
+    rec = pack_records(batched, fields)
+    dev = rec.device
+    if image_index is None:
+        image_index = torch.zeros(rec.shape[0], dtype=torch.long, device=dev)
+    assert rec.shape[0] <= capacity, (rec.shape[0], capacity)
+    padded = torch.zeros(capacity, rec.shape[1] + 1, dtype=rec.dtype, device=dev)
+    padded[: rec.shape[0], :-1] = rec
+    padded[: rec.shape[0], -1] = image_index.to(dev).float() + image_offset
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    mine = torch.tensor([rec.shape[0]], dtype=torch.int64, device=dev)
+    gathered = torch.empty(world * capacity, padded.shape[1], dtype=rec.dtype, device=dev)
+    works = [dist.all_gather_into_tensor(counts, mine, group=group, async_op=True),
+             dist.all_gather_into_tensor(gathered, padded, group=group, async_op=True)]
+    return PendingGather(works, gathered, counts, capacity, world, fields)
+
+
 def persons_from_batched(batched: dict, fields=RECORD) -> list:
     """[P, ...] tensors -> the reference's list of per-person dicts (model.py:329-347)."""
     P = batched[fields[0][0]].shape[0]

@@ -30,6 +30,10 @@ def _worker(rank, world, port, counts, q):
     glob_ids = [b for b in imgs for _ in range(counts[b])]
     batched = _fake_persons(glob_ids)
     out, img = collate.allgather_persons(batched, image_offset=imgs.start, image_index=torch.tensor(local_ids, dtype=torch.long), fields=FIELDS)
+    pend = collate.allgather_persons_async(batched, capacity=8, image_offset=imgs.start, image_index=torch.tensor(local_ids, dtype=torch.long),
+                                           fields=FIELDS)
+    out2, img2 = pend.wait()                      # the fixed-capacity asynchronous exchange gives the same collation
+    assert torch.equal(img2, img) and all(torch.equal(out2[k], out[k]) for k in out)
     if rank == 0:
         q.put(({k: v.clone() for k, v in out.items()}, img.clone()))
     dist.barrier()

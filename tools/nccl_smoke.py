@@ -21,6 +21,10 @@ tot = sum(3 + r for r in range(world))
 assert out["v3d"].shape == (tot, 10475, 3) and img.shape == (tot,), (out["v3d"].shape, img.shape)
 lo = sum(3 + r for r in range(rank))
 assert torch.equal(out["v3d"][lo: lo + P], batched["v3d"]) and torch.equal(out["scores"][lo: lo + P], batched["scores"])
+pend = collate.allgather_persons_async(batched, capacity=16, image_offset=rank * 4, image_index=torch.arange(P, device=dev) % 4)
+y = torch.randn(2048, 2048, device=dev) * 2.0          # other work enqueued while the collectives are in flight
+out2, img2 = pend.wait()
+assert torch.equal(img2, img) and all(torch.equal(out2[k], out[k]) for k in out)
 if rank == 0:
     print(f"RCCL collation OK: world {world}, {tot} persons, record width {collate.record_width()} floats")
 torch.distributed.destroy_process_group()
