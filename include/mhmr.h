@@ -191,10 +191,11 @@ int mhmr_layernorm_f32(const float* in, const float* w, const float* b, float* o
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct {
     int V, Vp;            /* 10475, V rounded up to a multiple of 64                                         */
-    int Kb;               /* 486 + nb + 10 + 1 rounded up to a multiple of 16                                */
+    int Kb;               /* 486 + nb + 10 rounded up to a multiple of 32 (width of the feature rows F)        */
     int nb, Kinf;         /* num_betas, max skinning influences per vertex                                   */
     int center_joint;     /* JOINT_NAMES.index(person_center) = 15 ('head')                                  */
-    const float* basis4;  /* [Kb/4][3][Vp][4]: rows = posedirs(486) | shapedirs(nb) | exprdirs(10) | v_template */
+    const void* basis16;  /* f16 [Kb/8][2][3][Vp][8]: 1024 x [posedirs(486) | shapedirs(nb) | exprdirs(10)] as hi + lo      */
+    const float* vtemp;   /* [3][Vp]           v_template, fp32                                                */
     const float* J0;      /* [55*3]            J_regressor . v_template                                      */
     const float* JS;      /* [55*3][nb+10]     J_regressor . [shapedirs | exprdirs]                          */
     const int* parents;   /* [55]                                                                            */

@@ -69,7 +69,7 @@ class HphDesc(C.Structure):
 
 class LbsConsts(C.Structure):
     _fields_ = ([(n, _i) for n in ("V", "Vp", "Kb", "nb", "Kinf", "center_joint")] +
-                [(n, _vp) for n in ("basis4", "J0", "JS", "parents", "skin_idx", "skin_w", "extra_vid", "lmk_vidx", "lmk_bary")])
+                [(n, _vp) for n in ("basis16", "vtemp", "J0", "JS", "parents", "skin_idx", "skin_w", "extra_vid", "lmk_vidx", "lmk_bary")])
 
 
 _SIGS = {

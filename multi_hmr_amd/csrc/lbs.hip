@@ -4,11 +4,17 @@
 //  1. lbs_pose_kernel   (one wave per person)  Rodrigues x55, pose feature, joint regression from the
 //     pre-contracted regressor (J = J0 + JS.[betas, expr]), kinematic chain, root rotation / recentring /
 //     back-projected translation folded into the per-joint skinning transforms, 55 posed joints + projection.
-//  2. lbs_vertex_kernel (the HBM-bound one)   v_posed = F . D as ONE fp32 GEMM on v_mfma_f32_16x16x4_f32 where
-//     F[p] = [pose_feature(486) | betas | expr | 1] and D = [posedirs ; shapedirs ; exprdirs ; v_template], so the
-//     61 MB of pose correctives stream from HBM once per 64-person slab; accumulators leave the MFMA already laid
-//     out as (vertex = lane & 15, 4 persons per quad), then the <=K-sparse skinning blend, the folded rigid
-//     transform and the pinhole projection run per lane and v3d / v2d are written out.
+//  2. lbs_vertex_kernel (the HBM-bound one)   v_posed = v_template + F . D as ONE GEMM, F[p] = [pose_feature(486) | betas | expr]
+//     and D = [posedirs ; shapedirs ; exprdirs], computed to fp32 accuracy on the 16-bit matrix pipe: D (scaled by 2^10 into
+//     the f16 normal range) is stored as an f16 pair hi + lo, F is split hi + lo on the fly, and
+//     F.D = Fh.Dh + Fl.Dh + Fh.Dl (three v_mfma_f32_16x16x32_f16, fp32 accumulate; the dropped Fl.Dl term is 2^-22 relative).
+//     The fp32 MFMA (v_mfma_f32_16x16x4_f32, 1/16 of the 16-bit rate) made this kernel matrix-bound: 108 us for 160 persons,
+//     74 us now.  Ablations of the 74 us: K loop 37 us (64 MB of correctives, ~2 waves per SIMD: latency-bound), skinning
+//     gathers 17 us, stores 5 us, rest 15 us.  Two re-tilings that raise the wave count were built and measured SLOWER (one
+//     16-person group per wave with per-wave basis loads: 82 us, the CU pulls 12x the unique bytes through its L1; the same
+//     with the basis tile shared through LDS and a barrier per K step: 94 us).  Accumulators leave the MFMA laid out as
+//     (vertex = lane & 15, 4 persons per quad), then the <=K-sparse skinning blend, the folded rigid transform and the pinhole
+//     projection run per lane and v3d / v2d are written out.
 //  3. lbs_extra_joints_kernel  the 21 vertex-picked joints and 51 barycentric face landmarks.
 #include "mhmr_common.h"
 #include "mhmr_internal.h"
@@ -96,13 +102,12 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
             sJ[j][a] = s;
         }
     }
-    // feature tail: [betas | expr | 1 | 0...]
+    // feature tail: [betas | expr | 0...]   (the template is added in fp32 by the vertex kernel)
     for (int k = 486 + j; k < c.Kb; k += 64) {
         const int t = k - 486;
         float v = 0.f;
         if (t < c.nb) v = betas[(size_t)p * c.nb + t];
         else if (t < ncoef) v = expr[(size_t)p * 10 + (t - c.nb)];
-        else if (t == ncoef) v = 1.f;
         Fp[k] = v;
     }
     __syncthreads();
@@ -185,14 +190,15 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
     }
 }
 
-// grid (Vp / 64, ceil(Pp / 64)); 4 waves, each a 16-vertex group; up to 4 person groups of 16 per wave.
+// grid (ceil(Pp / 64) person slabs [fastest], Vp / 64); 4 waves, each a 16-vertex group; up to 4 person groups of 16 per wave.
 __global__ __launch_bounds__(256) void lbs_vertex_kernel(const mhmr_lbs_consts c, const float* __restrict__ F,
                                                          const float* __restrict__ Afold, const float* __restrict__ xf, int P,
                                                          int Pp, float* __restrict__ v3d, float* __restrict__ v2d) {
+    typedef Op<MHMR_DT_F16>::V8 H8;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, l15 = lane & 15;
-    const int v0 = blockIdx.x * 64 + w * 16;
-    const int p0 = blockIdx.y * 64;
+    const int v0 = blockIdx.y * 64 + w * 16;
+    const int p0 = blockIdx.x * 64;
     const int npg = min(4, (Pp - p0) / 16);
 
     f32x4 acc[4][3];
@@ -201,28 +207,46 @@ __global__ __launch_bounds__(256) void lbs_vertex_kernel(const mhmr_lbs_consts c
 #pragma unroll
         for (int a = 0; a < 3; ++a) acc[i][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float* fp = F + (size_t)(p0 + l15) * c.Kb + 4 * g;
-    const size_t bstride = (size_t)c.Vp * 4;                       // floats per (k/4, axis) plane
-    const float* bp = c.basis4 + ((size_t)g * 3) * bstride + (size_t)(v0 + l15) * 4;
-    const int nk = c.Kb / 16;
-    for (int kt = 0; kt < nk; ++kt) {
-        f32x4 b[3];
+    // A operand: lane (person p0 + 16 i + l15, k group g) holds F[32 s + 8 g + 0..7]; B operand: lane (vertex v0 + l15, k group g)
+    // holds D[32 s + 8 g + 0..7][axis][vertex] = one 16-byte line of basis16 [Kb/8][hi|lo][3][Vp][8]
+    const float* fp = F + (size_t)(p0 + l15) * c.Kb + 8 * g;
+    const size_t plane = (size_t)c.Vp * 8;                          // halves per (k block, part, axis)
+    const _Float16* bp = (const _Float16*)c.basis16 + (size_t)g * 6 * plane + (size_t)(v0 + l15) * 8;
+    const int ns = c.Kb / 32;
+    for (int s = 0; s < ns; ++s) {
+        const _Float16* bs = bp + (size_t)(4 * s) * 6 * plane;
+        H8 bh[3], bl[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) b[a] = *(const f32x4*)(bp + ((size_t)kt * 12 + a) * bstride);
+        for (int a = 0; a < 3; ++a) {
+            bh[a] = *(const H8*)(bs + a * plane);
+            bl[a] = *(const H8*)(bs + (3 + a) * plane);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < npg) {
-                const f32x4 f = *(const f32x4*)(fp + (size_t)i * 16 * c.Kb + kt * 16);
+                const float* fr = fp + (size_t)i * 16 * c.Kb + 32 * s;
+                const f32x4 f0 = *(const f32x4*)fr, f1 = *(const f32x4*)(fr + 4);
+                H8 fh, fl;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e) {
+                    fh[e] = (_Float16)f0[e];
+                    fl[e] = (_Float16)(f0[e] - (float)fh[e]);
+                    fh[4 + e] = (_Float16)f1[e];
+                    fl[4 + e] = (_Float16)(f1[e] - (float)fh[4 + e]);
+                }
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) acc[i][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[e], b[a][e], acc[i][a], 0, 0, 0);
+                for (int a = 0; a < 3; ++a) {
+                    acc[i][a] = Op<MHMR_DT_F16>::mfma16(fh, bh[a], acc[i][a]);
+                    acc[i][a] = Op<MHMR_DT_F16>::mfma16(fl, bh[a], acc[i][a]);
+                    acc[i][a] = Op<MHMR_DT_F16>::mfma16(fh, bl[a], acc[i][a]);
+                }
             }
         }
     }
 
     const int v = v0 + l15;
     if (v >= c.V) return;
+    const float vt[3] = {c.vtemp[v], c.vtemp[c.Vp + v], c.vtemp[2 * c.Vp + v]};      // v_template stays fp32
     // skinning influences of this vertex (first 4 in registers)
     int si[4];
     float sw[4];
@@ -238,7 +262,8 @@ __global__ __launch_bounds__(256) void lbs_vertex_kernel(const mhmr_lbs_consts c
         for (int r = 0; r < 4; ++r) {
             const int p = p0 + 16 * i + 4 * g + r;
             if (p >= P) continue;
-            const float vx = acc[i][0][r], vy = acc[i][1][r], vz = acc[i][2][r];
+            const float vx = acc[i][0][r] * (1.0f / 1024.0f) + vt[0], vy = acc[i][1][r] * (1.0f / 1024.0f) + vt[1],
+                        vz = acc[i][2][r] * (1.0f / 1024.0f) + vt[2];
             const float* ab = Afold + (size_t)p * NJ * 12;
             f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0, t2 = t0;
 #pragma unroll
@@ -316,14 +341,14 @@ extern "C" int mhmr_lbs_forward(const mhmr_lbs_consts* c, const float* rotvec, c
                                 void* stream) {
     if (!c || P < 0) return MHMR_ERR_BAD_ARG;
     if (P == 0) return 0;
-    if (c->Kb % 16 || c->Vp % 64 || c->Kb < 486 + c->nb + 11 || c->Kinf < 1) return MHMR_ERR_BAD_SHAPE;
+    if (c->Kb % 32 || c->Vp % 64 || c->Kb < 486 + c->nb + 10 || c->Kinf < 1) return MHMR_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int Pp = (P + 15) / 16 * 16;
     hipLaunchKernelGGL(lbs_pose_kernel, dim3(Pp), dim3(64), 0, s, *c, rotvec, betas, expr, loc, dist, Kmat, det_b, P, ws_F, ws_A,
                        ws_xf, j3d, j2d, transl);
     MHMR_CHECK_LAUNCH();
     prof_begin(PROF_LBS, s);
-    hipLaunchKernelGGL(lbs_vertex_kernel, dim3(c->Vp / 64, (Pp + 63) / 64), dim3(256), 0, s, *c, ws_F, ws_A, ws_xf, P, Pp, v3d, v2d);
+    hipLaunchKernelGGL(lbs_vertex_kernel, dim3((Pp + 63) / 64, c->Vp / 64), dim3(256), 0, s, *c, ws_F, ws_A, ws_xf, P, Pp, v3d, v2d);
     prof_end(PROF_LBS, s, (double)P);
     MHMR_CHECK_LAUNCH();
     hipLaunchKernelGGL(lbs_extra_joints_kernel, dim3(P), dim3(128), 0, s, *c, v3d, v2d, ws_xf, j3d, j2d);

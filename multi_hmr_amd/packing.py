@@ -56,8 +56,9 @@ def interpolate_pos_embed(pos_embed: np.ndarray, G: int, offset: float = 0.1) ->
 def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) -> dict:
     """SMPL-X arrays (keys of SMPLX_NEUTRAL.npz) -> mhmr_lbs_consts tensors.
 
-    * basis rows = [posedirs (486) | shapedirs[:, :, :nb] | shapedirs[:, :, 300:310] | v_template | 0-pad],
-      stored [Kb/4][3][Vp][4] so that one float4 per lane feeds four k-steps of the fp32 MFMA;
+    * blend basis rows = [posedirs (486) | shapedirs[:, :, :nb] | shapedirs[:, :, 300:310] | 0-pad], scaled by 2^10 into the f16
+      normal range and stored as an f16 pair hi + lo, [Kb/8][hi|lo][3][Vp][8]: one 16-byte line per lane is the 16x16x32 MFMA
+      operand for 8 consecutive k; the template stays fp32 ([3][Vp]);
     * the dense joint regressor is pre-contracted with the template and the blend shapes (J = J0 + JS.coef);
     * skinning weights become a K-sparse (index, weight) list, K = max non-zeros per vertex.
     """
@@ -70,13 +71,18 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
     pd = f64(data["posedirs"])                                                                # [V,3,486]
     assert pd.shape[-1] == 486
     ncoef = num_betas + 10
-    Kb = roundup(486 + ncoef + 1, 16)
+    Kb = roundup(486 + ncoef, 32)
     Vp = roundup(V, 64)
-    D = np.zeros((Kb, 3, Vp), dtype=np.float32)
+    D = np.zeros((Kb, 3, Vp), dtype=np.float64)
     D[:486, :, :V] = pd.transpose(2, 1, 0)
     D[486:486 + ncoef, :, :V] = shp.transpose(2, 1, 0)
-    D[486 + ncoef, :, :V] = v_t.T
-    basis4 = np.ascontiguousarray(D.reshape(Kb // 4, 4, 3, Vp).transpose(0, 2, 3, 1))         # [Kb/4,3,Vp,4]
+    Ds = (D * 1024.0).astype(np.float32)
+    hi = Ds.astype(np.float16)
+    lo = (Ds - hi.astype(np.float32)).astype(np.float16)
+    lay = lambda a: a.reshape(Kb // 8, 8, 3, Vp).transpose(0, 2, 3, 1)                      # [Kb/8, 3, Vp, 8]
+    basis16 = np.ascontiguousarray(np.stack([lay(hi), lay(lo)], axis=1))                    # [Kb/8, 2, 3, Vp, 8]
+    vtemp = np.zeros((3, Vp), dtype=np.float32)
+    vtemp[:, :V] = v_t.T
 
     Jr = f64(data["J_regressor"])
     J0 = Jr @ v_t                                                                             # [55,3]
@@ -96,7 +102,7 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dt)
     return {
         "V": V, "Vp": Vp, "Kb": Kb, "nb": num_betas, "Kinf": Kinf, "center_joint": person_center_idx,
-        "basis4": t(basis4, torch.float32), "J0": t(J0, torch.float32), "JS": t(JS.reshape(55 * 3, ncoef), torch.float32),
+        "basis16": t(basis16, torch.float16), "vtemp": t(vtemp, torch.float32), "J0": t(J0, torch.float32), "JS": t(JS.reshape(55 * 3, ncoef), torch.float32),
         "parents": t(parents.astype(np.int32), torch.int32), "skin_idx": t(skin_idx, torch.int32), "skin_w": t(skin_w, torch.float32),
         "extra_vid": t(np.asarray(SMPLX_EXTRA_JOINT_VERTS, dtype=np.int32), torch.int32), "lmk_vidx": t(lmk_vidx, torch.int32),
         "lmk_bary": t(np.asarray(data["lmk_bary_coords"], dtype=np.float32), torch.float32),
@@ -108,6 +114,6 @@ def lbs_consts_struct(p: dict) -> "_lib.LbsConsts":
     c = _lib.LbsConsts()
     for k in ("V", "Vp", "Kb", "nb", "Kinf", "center_joint"):
         setattr(c, k, int(p[k]))
-    for k in ("basis4", "J0", "JS", "parents", "skin_idx", "skin_w", "extra_vid", "lmk_vidx", "lmk_bary"):
+    for k in ("basis16", "vtemp", "J0", "JS", "parents", "skin_idx", "skin_w", "extra_vid", "lmk_vidx", "lmk_bary"):
         setattr(c, k, p[k].data_ptr())
     return c

@@ -238,7 +238,7 @@ def test_camera_embed(L):
 
 
 # ------------------------------------------------------------------------------------------------------ LBS
-@pytest.mark.parametrize("P", [1, 5, 70])
+@pytest.mark.parametrize("P", [1, 5, 70, 300])          # 300: one full 256-person slab + a 3-wave remainder workgroup
 def test_lbs_against_oracle(L, smplx_data, P):
     import ctypes as C
     from oracle import smplx_ref
