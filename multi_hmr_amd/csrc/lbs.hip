@@ -12,7 +12,8 @@
 //     74 us now.  Ablations of the 74 us: K loop 37 us (64 MB of correctives, ~2 waves per SIMD: latency-bound), skinning
 //     gathers 17 us, stores 5 us, rest 15 us.  Two re-tilings that raise the wave count were built and measured SLOWER (one
 //     16-person group per wave with per-wave basis loads: 82 us, the CU pulls 12x the unique bytes through its L1; the same
-//     with the basis tile shared through LDS and a barrier per K step: 94 us).  Accumulators leave the MFMA laid out as
+//     with the basis tile shared through LDS and a barrier per K step: 94 us; with a 4-slot LDS-DMA ring three steps ahead: 83 us at
+//     160 persons although 23 instead of 32 us at 20 -- the per-wave skinning set-up then repeats for every 16 persons).  Accumulators leave the MFMA laid out as
 //     (vertex = lane & 15, 4 persons per quad), then the <=K-sparse skinning blend, the folded rigid transform and the pinhole
 //     projection run per lane and v3d / v2d are written out.
 //  3. lbs_extra_joints_kernel  the 21 vertex-picked joints and 51 barycentric face landmarks.
