@@ -38,6 +38,10 @@ extern "C" {
 #define MHMR_EPI_PATCH 4     /* patch-embed: + bias + pos-embed, scattered to token rows     */
 #define MHMR_EPI_F32 5       /* out32 = acc (+ bias)                    (HPH to_kv)          */
 #define MHMR_EPI_VT 6        /* V^T[b][h][d][swap23(t)] = acc + bias    (attention V operand) */
+#define MHMR_EPI_OP16_QK 7   /* out16 = (acc + bias) * (n < N/2 ? MHMR_ATTN_QSCALE : 1): the Q | K projection (N = 2C) with the
+                                softmax scale and the exp -> exp2 change of base folded into Q in fp32, before the one rounding */
+/* head_dim^-0.5 * log2(e) for head_dim = 64 (DINOv2 Attention: softmax((q * scale) k^T)) */
+#define MHMR_ATTN_QSCALE 0.18033688011112042f
 
 int mhmr_version(void);
 
@@ -77,6 +81,7 @@ typedef struct {
     void* vt;               /* op16 [B, H, 64, Tp]                                                        */
     void* att;              /* op16 [B*Tp, C]                                                             */
     void* hid;              /* op16 [B*Tp, 4C]                                                            */
+    int* attn_flags;        /* [mhmr_attention_flag_count(B, Tp, H)] or NULL (then the self-contained attention form runs) */
 } mhmr_vit_desc;
 
 /* x: [B,3,S,S] fp32 (ImageNet-normalised).  feat32: [B*N, C] fp32 patch features (token n = y*G + x).
@@ -87,8 +92,22 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
 int mhmr_gemm16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias,
                 const float* gamma, void* out, int ldo, const float* pos, int Np, int Tp, int H, int Mvalid, int epi,
                 int dtype, void* stream);
+/* qk: op16 [B*Tp, 2C] = (Q * MHMR_ATTN_QSCALE | K), head h at columns h*64; vt: op16 [B,H,64,Tp] key-permuted V^T
+ * (MHMR_EPI_VT); out: op16 [B*Tp, C] = softmax_2(Q K^T) V over the T real keys of each image.                    */
 int mhmr_attention16(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype,
                      void* stream);
+/* The attention kernel forms (csrc/attention.hip), for tests and A/B measurements.  Every form subtracts a per-query reference
+ * level from the scores inside the matrix pipe; they differ in how the level follows the row maximum:
+ *   variant 0  (what mhmr_vit_forward runs) level = exact row maximum of key tile 0, no maximum afterwards; a workgroup in which
+ *              a lane's tile sum of exp2(score - level) exceeded 2^limit_log2 (0 <= limit_log2 <= 15; 15 = "would leave the
+ *              16-bit range", 0 = nearly every workgroup) sets its entry of `flags` and is recomputed by variant 1, launched
+ *              right behind it on the same stream.  flags: int workspace of mhmr_attention_flag_count(B, Tp, H) entries.
+ *   variant 1  textbook online softmax (running maximum + subtract every tile).        flags unused (NULL)
+ *   variant 2  level moves when the running maximum leaves a +-8 band (what mhmr_attention16 runs).   flags unused (NULL)
+ *   variant 3  variant 2 with 8-wave workgroups.                                        flags unused (NULL)              */
+int mhmr_attention16_ex(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype,
+                        float limit_log2, int variant, int* flags, void* stream);
+int mhmr_attention_flag_count(int B, int Tp, int H);
 int mhmr_layernorm16(const float* in, const float* w, const float* b, void* out16, int rows, int C, float eps,
                      int dtype, void* stream);
 
@@ -193,7 +212,8 @@ typedef struct {
     int V, Vp;            /* 10475, V rounded up to a multiple of 64                                         */
     int Kb;               /* 486 + nb + 10 rounded up to a multiple of 32 (width of the feature rows F)        */
     int nb, Kinf;         /* num_betas, max skinning influences per vertex                                   */
-    int center_joint;     /* JOINT_NAMES.index(person_center) = 15 ('head')                                  */
+    int center_joint;     /* JOINT_NAMES.index(person_center) = 15 ('head'); < 0 = person_center None: nothing is
+                             recentred and the pelvis is added to the translation (smpl_layer.py:128-130)       */
     const void* basis16;  /* f16 [Kb/8][2][3][Vp][8]: 1024 x [posedirs(486) | shapedirs(nb) | exprdirs(10)] as hi + lo      */
     const float* vtemp;   /* [3][Vp]           v_template, fp32                                                */
     const float* J0;      /* [55*3]            J_regressor . v_template                                      */

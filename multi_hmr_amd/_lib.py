@@ -17,7 +17,8 @@ HEADERS = ["mhmr_common.h", "mhmr_internal.h", os.path.join("..", "..", "include
 
 DT_BF16, DT_F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-EPI_OP16, EPI_OP16_GELU, EPI_OP16_RELU, EPI_RESID, EPI_PATCH, EPI_F32, EPI_VT = range(7)
+EPI_OP16, EPI_OP16_GELU, EPI_OP16_RELU, EPI_RESID, EPI_PATCH, EPI_F32, EPI_VT, EPI_OP16_QK = range(8)
+ATTN_QSCALE = 0.18033688011112042   # include/mhmr.h MHMR_ATTN_QSCALE
 
 _vp, _fp, _ip, _i, _f = C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float  # all device pointers are void*
 
@@ -51,7 +52,7 @@ class VitDesc(C.Structure):
     _fields_ = ([(n, _i) for n in ("dtype", "B", "S", "C", "H", "L", "G", "N", "T", "Tp", "Kp")] +
                 [("patch_w", _vp), ("patch_b", _vp), ("cls_pos0", _vp), ("pos", _vp), ("blocks", C.POINTER(VitBlock)),
                  ("norm_w", _vp), ("norm_b", _vp)] +
-                [(n, _vp) for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid")])
+                [(n, _vp) for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid", "attn_flags")])
 
 
 class HphLayer(C.Structure):
@@ -77,6 +78,8 @@ _SIGS = {
     "mhmr_vit_forward": ([C.POINTER(VitDesc), _vp, _vp, _vp, _i, _vp], _i),
     "mhmr_gemm16": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mhmr_attention16": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "mhmr_attention16_ex": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp], _i),
+    "mhmr_attention_flag_count": ([_i, _i, _i], _i),
     "mhmr_layernorm16": ([_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp], _i),
     "mhmr_detect_scores": ([_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "mhmr_detect_count": ([_vp, _i, _i, _i, _f, _vp, _vp], _i),

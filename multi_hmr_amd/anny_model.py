@@ -24,9 +24,9 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import _lib, packing, synthetic
+from . import _lib, packing, synthetic, vit
 from .anny_hph import HPH
-from .model import PATCH, _Encoder, _Holder, C_cast_blocks
+from .model import PATCH, _Encoder, _Holder
 from .packing import roundup
 from .synthetic import VIT_CFG
 
@@ -86,51 +86,32 @@ class Multi_HMR(nn.Module):
         self.eye = nn.Parameter(torch.eye(3).unsqueeze(0), requires_grad=False)
         self.useful_rotmat = nn.Parameter(torch.tensor(synthetic.ANNY_USEFUL_ROTMAT).unsqueeze(0), requires_grad=False)
         self.register_buffer("init_body_pose", synthetic.anny_init_body_pose())
-        self._packed, self._ws = None, {}
+        self._packed, self._ws = None, vit.WorkspaceCache()
         for p in self.parameters():
             p.requires_grad_(False)
 
     # ------------------------------------------------------------------------------------------------------ packing
     def load_state_dict(self, state_dict, strict=True, **kw):
-        self._packed = None
+        self.repack()
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
     def _apply(self, fn, *a, **k):
-        self._packed, self._ws = None, {}
+        self.repack()
         return super()._apply(fn, *a, **k)
 
+    def repack(self):
+        """Drop the packed weights and the workspace whose descriptor points into them."""
+        self._packed = None
+        self._ws.clear()
+
     def _pack(self, device):
-        dt_id, tdt = packing.OP_DTYPES[self.precision]
+        self._ws.clear()
         enc = self.encoder.backbone
-        Cd, H, L = enc.embed_dim, enc.num_heads, len(enc.blocks)
-        G = self.img_size // PATCH
-        N, T = G * G, G * G + 1
+        P = vit.pack_encoder(enc, self.img_size, self.precision, device)
+        tdt, Cd = P["tdt"], P["C"]
+        P["Kc"] = roundup(Cd, 64)
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         op = lambda t: t.detach().to(device=device, dtype=torch.float32).to(tdt).contiguous()
-        keep = []
-
-        def k(t):
-            keep.append(t)
-            return t.data_ptr()
-
-        P = {"dt_id": dt_id, "tdt": tdt, "C": Cd, "H": H, "L": L, "G": G, "N": N, "T": T, "Tp": roundup(T, 128), "Kp": 640,
-             "Kc": roundup(Cd, 64), "device": device}
-        pos = torch.from_numpy(packing.interpolate_pos_embed(enc.pos_embed.detach().float().cpu().numpy(), G)).to(device)
-        cls_pos0 = f32(enc.cls_token.reshape(-1)) + pos[0]
-        pw = torch.zeros(Cd, P["Kp"], dtype=torch.float32, device=device)
-        pw[:, :588] = f32(enc.patch_embed.proj.weight).reshape(Cd, 588)
-        blocks = (_lib.VitBlock * L)()
-        for i, b in enumerate(enc.blocks):
-            blk = blocks[i]
-            blk.ln1_w, blk.ln1_b = k(f32(b.norm1.weight)), k(f32(b.norm1.bias))
-            blk.qkv_w, blk.qkv_b = k(op(b.attn.qkv.weight)), k(f32(b.attn.qkv.bias))
-            blk.proj_w, blk.proj_b, blk.ls1 = k(op(b.attn.proj.weight)), k(f32(b.attn.proj.bias)), k(f32(b.ls1.gamma))
-            blk.ln2_w, blk.ln2_b = k(f32(b.norm2.weight)), k(f32(b.norm2.bias))
-            blk.fc1_w, blk.fc1_b = k(op(b.mlp.fc1.weight)), k(f32(b.mlp.fc1.bias))
-            blk.fc2_w, blk.fc2_b, blk.ls2 = k(op(b.mlp.fc2.weight)), k(f32(b.mlp.fc2.bias)), k(f32(b.ls2.gamma))
-        P["vit"] = dict(blocks=blocks, patch_w=k(pw.to(tdt).contiguous()), patch_b=k(f32(enc.patch_embed.proj.bias)),
-                        cls_pos0=k(cls_pos0.contiguous()), pos=k(pos.contiguous()), norm_w=k(f32(enc.norm.weight)),
-                        norm_b=k(f32(enc.norm.bias)))
         e = self.encoder
         D, J = self.dec_to_token.out_features, self.n_joints
         P.update(D=D, det0_w=op(e.mlp_det[0].weight), det0_b=f32(e.mlp_det[0].bias), det2_w=f32(e.mlp_det[2].weight.reshape(-1)),
@@ -148,34 +129,16 @@ class Multi_HMR(nn.Module):
         for name in ("mlp_offset", "mlp_shape", "mlp_dist"):
             m = getattr(self, name)
             P[name] = (f32(m[0].weight), f32(m[0].bias), f32(m[2].weight), f32(m[2].bias))
-        P["keep"] = keep
         self._packed = P
         return P
 
     def _workspace(self, P, B):
-        ws = self._ws.get(B)
-        if ws is not None:
-            return ws
-        dev, tdt = P["device"], P["tdt"]
-        Cd, N, Tp, H = P["C"], P["N"], P["Tp"], P["H"]
-        Mp = roundup(B * N, 128)
-        z = lambda *s, dtype=tdt: torch.zeros(*s, dtype=dtype, device=dev)
-        ws = dict(a_patch=z(Mp, P["Kp"]), resid=z(B * Tp, Cd, dtype=torch.float32), xn=z(B * Tp, Cd), qk=z(B * Tp, 2 * Cd),
-                  vt=z(B * H * 64, Tp), att=z(B * Tp, Cd), hid=z(B * Tp, 4 * Cd), feat32=z(B * N, Cd, dtype=torch.float32),
-                  ctx16=z(Mp, P["Kc"]), hid_det=z(Mp, Cd), scores=z(B * N, dtype=torch.float32), logits=z(B * N, dtype=torch.float32),
-                  counts=z(B, dtype=torch.int32), dec_emb=z(1 + Mp, P["D"], dtype=torch.float32))
-        v = P["vit"]
-        d = _lib.VitDesc()
-        d.dtype, d.B, d.S, d.C, d.H, d.L = P["dt_id"], B, self.img_size, Cd, H, P["L"]
-        d.G, d.N, d.T, d.Tp, d.Kp = P["G"], N, P["T"], Tp, P["Kp"]
-        d.patch_w, d.patch_b, d.cls_pos0, d.pos = v["patch_w"], v["patch_b"], v["cls_pos0"], v["pos"]
-        d.blocks = C_cast_blocks(v["blocks"])
-        d.norm_w, d.norm_b = v["norm_w"], v["norm_b"]
-        for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid"):
-            setattr(d, n, ws[n].data_ptr())
-        ws["vit_desc"] = d
-        self._ws[B] = ws
-        return ws
+        def extra(P, B, z):
+            Mp = roundup(B * P["N"], 128)
+            return dict(ctx16=z(Mp, P["Kc"]), hid_det=z(Mp, P["C"]), scores=z(B * P["N"], dtype=torch.float32),
+                        logits=z(B * P["N"], dtype=torch.float32), counts=z(B, dtype=torch.int32),
+                        dec_emb=z(1 + Mp, P["D"], dtype=torch.float32))
+        return self._ws.get(P, B, extra)
 
     # ------------------------------------------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -219,7 +182,7 @@ class Multi_HMR(nn.Module):
                                  ws["hid_det"].data_ptr(), Cd, None, 0, Tp, 1, Mp, _lib.EPI_OP16_RELU, P["dt_id"], st), "mlp_det.0")
         _lib.check(L.mhmr_anny_scores(ws["hid_det"].data_ptr(), Cd, P["det2_w"].data_ptr(), P["det2_b"].data_ptr(), ws["scores"].data_ptr(),
                                       ws["logits"].data_ptr(), B * N, Cd, P["dt_id"], st), "mhmr_anny_scores")
-        scores = ws["scores"].view(B, G, G)
+        scores = ws["scores"].view(B, G, G).clone()          # outputs never alias the per-batch workspace (the next forward rewrites it)
         scores_logits = ws["logits"].view(B, G, G).clone()
 
         # ---- detections (multi_hmr.py:117-124) ----
@@ -282,7 +245,7 @@ class Multi_HMR(nn.Module):
 
         out = {"scores": scores, "scores_logits": scores_logits, "K": Kmat, "K_regressed": K_reg, "fov_regressed": fov, "loc": loc,
                "offset": offset, "dist": dist, "dist_postprocessed": dist_logit, "shape": shape, "rotvec": rotvec, "rotmat": rotmat,
-               "transl": transl, "feat": ws["feat32"].view(B, G, G, Cd)}
+               "transl": transl, "feat": ws["feat32"].view(B, G, G, Cd).clone()}
         if self.body_model is not None:          # multi_hmr.py:160-182, with the caller's anny model
             _shape = {k: shape[:, l] for l, k in enumerate(self.body_model.phenotype_labels) if k in PHENOTYPE_KEYS}
             homo = torch.zeros(Pn, J, 4, 4, device=dev)

@@ -1,6 +1,10 @@
 // Flash-style multi-head self-attention forward for the DINOv2 blocks, head_dim = 64, non-causal,
 // T = N + 1 tokens padded to Tp (multiple of 128); keys >= T are masked.
 //
+// Input contract: the Q half of `qk` arrives PRE-SCALED by MHMR_ATTN_QSCALE = 0.125 * log2(e) (the QK projection's epilogue
+// multiplies in fp32 before the one rounding to 16 bits, MHMR_EPI_OP16_QK), so the scores leave the matrix pipe already in the
+// exp2 domain and the softmax needs no per-element multiply.
+//
 // gfx950 structure: one workgroup = 4 waves = 128 query rows of one (image, head); each wave owns 32 query
 // rows.  Per 64-key tile:  S^T = K . Q^T  (8 x v_mfma_f32_32x32x16, "swapped" so a lane owns ONE query column
 // and 32 of the 64 keys -> row max / row sum are lane-local plus one lane^32 exchange), online softmax in
@@ -8,12 +12,31 @@
 // already transposed and key-permuted (bits 2<->3 of the key index swapped inside every 16-key group, written
 // that way by the V GEMM epilogue), so the lane that holds P for keys {16s+4hi+0..3, 16s+8+4hi+0..3} reads the
 // matching V^T operand as ONE ds_read_b128 -- no cross-lane shuffle and no LDS transpose.
+//
+// Softmax.  The VALU, not the matrix pipe, bounds this kernel at d = 64: 16 MFMAs = 512 pipe cycles per tile beside ~400 VALU
+// cycles in the textbook online-softmax form (tools/ubench: exp 5.3, max / max3 / cvt_pk 2.85, add / sub / mov 1.8 SIMD cycles per
+// wave instruction at 4 waves per SIMD; one wave alone issues at most one VALU instruction per ~5.3 cycles).  The per-tile VALU
+// work is cut by keeping, per query, a reference level m_ref that is SUBTRACTED INSIDE THE MATRIX PIPE: the score accumulators
+// start at -m_ref instead of 0 (16 v_mov: both key halves take the same tuple as their first C operand), so p = exp2(s) needs
+// no per-element subtract or multiply, and m_ref only has to be NEAR the row maximum, not equal to it:
+//   MODE 2  m_ref moves when the running row maximum leaves [m_ref - 8, m_ref + 8] (wave-uniform branch; exact: O, l and the
+//           tile's scores are shifted by the same power of two).  Self-contained.
+//   MODE 3  m_ref = the exact row maximum of key tile 0, then fixed: no row maximum at all on later tiles.  Every p is positive,
+//           so "this lane's tile sum <= 2^15" proves every p of the lane finite in f16 / bf16; a wave that ever sees a larger
+//           sum (a later key beats tile 0's maximum by more than 2^15: rare) raises its workgroup's flag, and the textbook
+//           kernel (MODE 1), launched right behind on the same stream, recomputes exactly the flagged workgroups and returns at
+//           once everywhere else.
+//   MODE 1  textbook: exact running maximum and a per-element subtract every tile.
+// Nothing is approximated in any mode: p keeps its full significand at any magnitude, l and O accumulate in fp32, and O / l is
+// invariant to the reference level; the modes differ in rounding order only (tests: all three against fp64 on inputs that force
+// every branch).
+//
 // K and V^T tiles ([64][64] 16-bit = 128-byte rows) are DMA'd by global_load_lds_dwordx4 into a 2-slot LDS ring with
 // the chunk XOR swizzle on the source address, one tile ahead (the whole consume phase of tile j covers tile j+1's
-// flight); one barrier per KV tile; 32 KiB LDS and 114 VGPRs put 4 workgroups = 16 waves on a CU (measured +2.8 % over a
-// 3-slot ring at 3 workgroups/CU).  The landing wait is an EXPLICIT `s_waitcnt vmcnt(0)`: inside a loop hipcc
+// flight); one barrier per KV tile.  The landing wait is an EXPLICIT `s_waitcnt vmcnt(0)`: inside a loop hipcc
 // (ROCm 7.2) does NOT emit the vmcnt wait for LDS-DMA in front of __syncthreads() -- it hoisted it out of the loop -- and
 // the kernel then read tiles that had not landed (run-to-run different results; tools/determinism.py).
+#include <stdlib.h>
 #include "mhmr_common.h"
 #include "mhmr_internal.h"
 
@@ -27,22 +50,28 @@ __device__ __forceinline__ float max_lane32(float v) {
 
 constexpr int KB = 64;
 constexpr int KV_TILE_BYTES = KB * 64 * 2;  // 8 KiB
+constexpr float BAND = 8.f;                 // MODE 2: half-width of the band around the reference level (exp2 domain)
 
-// NW waves x 32 query rows per workgroup; RING K/V tile slots in LDS (tile j + RING - 1 is in flight while tile j is consumed)
-template <int DT, int NW, int RING>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(const void* __restrict__ qk_, const void* __restrict__ vt_,
-                                                      void* __restrict__ out_, int T, int Tp, int C, int H,
-                                                      int nqt, float scale_log2e) {
+// NW waves x 32 query rows per workgroup; RING K/V tile slots in LDS (tile j + RING - 1 is in flight while tile j is consumed).
+// flags: one int per workgroup (logical id).  MODE 3 sets flags[wg] = 1 when its result must be recomputed; MODE 1 with a
+// non-null flags pointer returns immediately unless flags[wg] != 0.
+template <int DT, int NW, int RING, int MODE>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
+    const void* __restrict__ qk_, const void* __restrict__ vt_, void* __restrict__ out_, int T, int Tp, int C, int H, int nqt,
+    float limit, int* __restrict__ flags) {
     typedef typename Op<DT>::T Tt;
     typedef typename Op<DT>::V8 V8;
     typedef typename Op<DT>::V4 V4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | Vt tile]
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [RING][K tile | Vt tile]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
 
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    if constexpr (MODE == 1) {
+        if (flags != nullptr && flags[bid] == 0) return;      // fallback launch: only the flagged workgroups are recomputed
+    }
     const int qt = bid % nqt, bh = bid / nqt;
     const int b = bh / H, h = bh - b * H;
 
@@ -89,7 +118,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(const vo
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;  // running max (scaled, log2 domain) and this lane's partial row sum
+    // m_ref: this query's reference level (exp2 domain; MODE 1: the exact running maximum); r_run (MODE 2): running row maximum
+    // relative to m_ref; l_run: this lane's partial row sum of exp2(s - m_ref)
+    float m_ref = MODE == 1 ? -1e30f : 0.f, r_run = -INFINITY, l_run = 0.f;
+    bool bad = false;                                         // MODE 3: a p may have left the 16-bit range
 
     const int ntile = (T + KB - 1) / KB;
 #pragma unroll
@@ -115,12 +147,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(const vo
             stage(j + RING - 1 < ntile ? j + RING - 1 : ntile - 1, nbuf_now);
             continue;
         }
-        // ---- S^T = K . Q^T ----
+        // ---- S^T = K . Q^T - m_ref ----
         f32x16 s[2];   // the two key halves alternate in issue order: back-to-back MFMAs never share an accumulator
+        {
+            const float init = MODE == 1 ? 0.f : -m_ref;
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+            for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+                for (int r = 0; r < 16; ++r) s[sub][r] = init;
+        }
         __builtin_amdgcn_s_setprio(1);   // matrix sections outrank the other waves' VALU work at the issue arbiter (+1-2 %)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -143,33 +178,73 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(const vo
                 for (int r = 0; r < 16; ++r)
                     if (j * KB + 32 * sub + crow(r, hi) >= T) s[sub][r] = -INFINITY;
         }
-        // ---- online softmax (one query row per lane pair {l, l^32}) ----
-        float mt = s[0][0];
+        // ---- reference level ----
+        if (MODE != 3 || j == 0) {
+            // row maximum of the tile (one query row per lane pair {l, l^32}); every tile holds at least one unmasked key
+            float mt = s[0][0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[0][r]);
+            for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[0][r]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[1][r]);
-        mt = max_lane32(mt);
-        const float m_new = fmaxf(m_run, mt * scale_log2e);
-        if (!__all(m_new == m_run)) {
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run *= alpha;
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[1][r]);
+            mt = max_lane32(mt);
+            if constexpr (MODE == 1) {
+                const float m_new = fmaxf(m_ref, mt);
+                if (!__all(m_new == m_ref)) {
+                    const float alpha = __builtin_amdgcn_exp2f(m_ref - m_new);
+                    l_run *= alpha;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-            m_run = m_new;
-        }
-        float psum = 0.f;
+                        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+                    m_ref = m_new;
+                }
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+                for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[sub][r] * scale_log2e - m_run);
-                s[sub][r] = p;
-                psum += p;
+                    for (int r = 0; r < 16; ++r) s[sub][r] -= m_ref;
+            } else if constexpr (MODE == 2) {
+                // exact: everything exponentiated against the old level (O, l) and the scores of THIS tile (not yet exponentiated)
+                // are shifted by the same delta
+                const float r_new = fmaxf(r_run, mt);
+                if (!__all(r_new <= BAND && r_new >= -BAND)) {
+                    const float delta = r_new;
+                    const float alpha = r_run == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(-delta);   // first tile: O = l = 0
+                    l_run *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[sub][r] -= delta;
+                    m_ref += delta;
+                    r_run = 0.f;
+                } else {
+                    r_run = r_new;
+                }
+            } else {        // MODE 3, tile 0 (m_ref = 0, O = l = 0): the level becomes the exact row maximum
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[sub][r] -= mt;
+                m_ref = mt;
             }
+        }
+        // ---- p = exp2(s - m_ref); two independent partial sums (one serial chain of 32 adds would pace the wave) ----
+        float psum0 = 0.f, psum1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p0 = __builtin_amdgcn_exp2f(s[0][r]);
+            const float p1 = __builtin_amdgcn_exp2f(s[1][r]);
+            s[0][r] = p0;
+            s[1][r] = p1;
+            psum0 += p0;
+            psum1 += p1;
+        }
+        const float psum = psum0 + psum1;
         l_run += psum;
+        if constexpr (MODE == 3) bad |= !(psum <= limit);     // all p > 0: a lane sum <= limit proves every p finite in 16 bits
 
         // ---- O^T += V^T . P^T ----
         __builtin_amdgcn_s_setprio(1);
@@ -188,6 +263,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(const vo
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (MODE == 3) {
+        if (__any(bad) && lane == 0) flags[bid] = 1;          // the MODE 1 launch behind this one recomputes the workgroup
+    }
     // ---- normalise and store: lane (q, hi) holds O[q][32 ds + 8 rg + 4 hi + 0..3] ----
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = active ? 1.0f / l_tot : 0.f;
@@ -204,37 +282,61 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(const vo
         }
 }
 
-
-}  // namespace
-
-template <int NW, int RING>
-static int launch_attn(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, hipStream_t s) {
+template <int NW, int RING, int MODE>
+int launch_attn(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit, int* flags,
+                hipStream_t s) {
     constexpr int QB = 32 * NW;
     const int nqt = (Tp + QB - 1) / QB;
     const int grid = nqt * H * B;
     const size_t lds = RING * 2 * KV_TILE_BYTES;
-    const float scale_log2e = 0.125f * 1.44269504088896340736f;
     if (dtype == MHMR_DT_F16)
-        hipLaunchKernelGGL((attn_kernel<MHMR_DT_F16, NW, RING>), dim3(grid), dim3(64 * NW), lds, s, qk, vt, out, T, Tp, C, H, nqt, scale_log2e);
+        hipLaunchKernelGGL((attn_kernel<MHMR_DT_F16, NW, RING, MODE>), dim3(grid), dim3(64 * NW), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags);
     else
-        hipLaunchKernelGGL((attn_kernel<MHMR_DT_BF16, NW, RING>), dim3(grid), dim3(64 * NW), lds, s, qk, vt, out, T, Tp, C, H, nqt, scale_log2e);
+        hipLaunchKernelGGL((attn_kernel<MHMR_DT_BF16, NW, RING, MODE>), dim3(grid), dim3(64 * NW), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags);
     return 0;
 }
 
-// Measured at ViT-L 896 b32 (tools/kbench.py): <4,2> 852, <4,3> 832, <8,2> 855, <8,3> 855-860, <8,4> 854 TFLOP/s -- halving the
-// L2->LDS traffic (NW = 8) or deepening the ring changes nothing: the kernel is bound by the per-wave issue mix (16 MFMA, ~150 VALU
-// incl. 32 v_exp, 16 ds_read_b128 per tile), and only waves/SIMD moved it (3 -> 4: +2.8 %).  <4,2> is the shipped configuration.
-// Role-structured variants were built, passed the parity and determinism tests, and lost: next tile's scores issued in the same
-// basic block as this tile's exps (two score tiles in registers, 3 waves/SIMD) 784; 8-wave two-group ping-pong (VALU phase /
-// 16-MFMA phase, fragments pre-read into registers) 640-740; 12-wave three-group rotation (one matrix wave + two VALU waves per
-// SIMD at any time, 4-slot ring) 795-822 TFLOP/s.  A lone wave issues VALU at ~5.5 cycles per instruction (tools/ubench), so the
-// softmax of one tile is 1100+ cycles beside 512 matrix-pipe cycles; four unsynchronised waves per SIMD hide that best.
-int mhmr_launch_attention(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype,
-                          hipStream_t s) {
-    if (C != H * 64 || Tp % 128 || T > Tp || T <= 0) return MHMR_ERR_BAD_SHAPE;
+}  // namespace
+
+// Number of ints of `flags` workspace the default attention form needs for a problem (one per workgroup).
+int mhmr_attention_flag_count_impl(int B, int Tp, int H) { return ((Tp + 127) / 128) * H * B; }
+
+// limit_log2 (variant 0): a workgroup is recomputed by the textbook kernel when a lane's tile sum of exp2(s - level) exceeded
+// 2^limit_log2 (0 <= limit_log2 <= 15; 15 = the shipped value "would leave the 16-bit range", 0 = nearly every workgroup).
+// variant: 0 = MODE 3 + gated MODE 1 fallback (needs `flags`), 1 = textbook (MODE 1), 2 = banded running maximum (MODE 2),
+// 3 = MODE 2 with 8-wave workgroups.
+// Measured at ViT-L 896 b32, f16 / bf16 TFLOP/s (tools/kbench.py, interleaved rounds): textbook 855-875 / 895-929; banded
+// maximum 930-940 / 973-1003; the same with the level as a 16-register C tuple (3 waves per SIMD) 918-920 / 975; with all 8 K
+// fragments and the V^T fragments requested ahead of their MFMAs (sched_barrier-pinned; 3 waves per SIMD, or 4 with spills)
+// 840-918: LDS latency is not what bounds the kernel, the VALU work per tile and the 128-register budget are (a form that kept
+// the exact rescale inside the loop next to the sum test needed all 128 registers and fell to one LDS read per MFMA: 850).
+int mhmr_launch_attention_ex(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit_log2,
+                             int variant, int* flags, hipStream_t s) {
+    if (C != H * 64 || Tp % 128 || T > Tp || T <= 0 || limit_log2 < 0.f || limit_log2 > 15.f) return MHMR_ERR_BAD_SHAPE;
+    if (variant == 0 && flags == nullptr) return MHMR_ERR_BAD_ARG;
+    const float limit = exp2f(limit_log2);
     prof_begin(PROF_ATTN, s);
-    launch_attn<4, 2>(qk, vt, out, B, T, Tp, C, H, dtype, s);
+    switch (variant) {
+        case 0: {
+            hipError_t e = hipMemsetAsync(flags, 0, sizeof(int) * (size_t)mhmr_attention_flag_count_impl(B, Tp, H), s);
+            if (e != hipSuccess) return (int)e;
+            launch_attn<4, 2, 3>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
+            launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);      // returns at once where flags[wg] == 0
+            break;
+        }
+        case 1: launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, nullptr, s); break;
+        case 2: launch_attn<4, 2, 2>(qk, vt, out, B, T, Tp, C, H, dtype, limit, nullptr, s); break;
+        case 3: launch_attn<8, 3, 2>(qk, vt, out, B, T, Tp, C, H, dtype, limit, nullptr, s); break;
+        default: return MHMR_ERR_BAD_ARG;
+    }
     prof_end(PROF_ATTN, s, 4.0 * B * H * (double)T * T * 64);
     MHMR_CHECK_LAUNCH();
     return 0;
+}
+
+int mhmr_launch_attention(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, int* flags,
+                          hipStream_t s) {
+    static const char* v = getenv("MHMR_ATTN_VARIANT");      // A/B measurements only
+    const int variant = v ? atoi(v) : (flags ? 0 : 2);
+    return mhmr_launch_attention_ex(qk, vt, out, B, T, Tp, C, H, dtype, 15.f, variant, flags, s);
 }

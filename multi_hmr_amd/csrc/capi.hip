@@ -6,7 +6,9 @@
 #include "mhmr_internal.h"
 
 // launchers defined in the other translation units
-int mhmr_launch_attention(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, hipStream_t s);
+int mhmr_launch_attention(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, int* flags, hipStream_t s);
+int mhmr_launch_attention_ex(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit_log2, int variant, int* flags, hipStream_t s);
+int mhmr_attention_flag_count_impl(int B, int Tp, int H);
 int mhmr_launch_im2col(const float* x, void* a, int B, int S, int G, int Kp, int dtype, hipStream_t s);
 int mhmr_launch_init_rows(float* resid, const float* cls_pos0, int B, int T, int Tp, int C, hipStream_t s);
 int mhmr_launch_layernorm(const float* in, const float* w, const float* b, void* out16, int rows, int C, float eps, int dtype, hipStream_t s);
@@ -99,8 +101,15 @@ int mhmr_gemm16(const void* A, int lda, const void* W, int ldw, int M, int N, in
 }
 
 int mhmr_attention16(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, void* stream) {
-    return mhmr_launch_attention(qk, vt, out, B, T, Tp, C, H, dtype, (hipStream_t)stream);
+    return mhmr_launch_attention(qk, vt, out, B, T, Tp, C, H, dtype, nullptr, (hipStream_t)stream);
 }
+
+int mhmr_attention16_ex(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit_log2,
+                        int variant, int* flags, void* stream) {
+    return mhmr_launch_attention_ex(qk, vt, out, B, T, Tp, C, H, dtype, limit_log2, variant, flags, (hipStream_t)stream);
+}
+
+int mhmr_attention_flag_count(int B, int Tp, int H) { return mhmr_attention_flag_count_impl(B, Tp, H); }
 
 int mhmr_layernorm16(const float* in, const float* w, const float* b, void* out16, int rows, int C, float eps, int dtype,
                      void* stream) {
@@ -130,13 +139,13 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
         // x = x + ls1 * proj(MHSA(norm1(x)))
         TRY(mhmr_launch_layernorm(d->resid, k.ln1_w, k.ln1_b, d->xn, M, C, 1e-6f, dt, s));
         {
-            GemmArgs g{d->xn, C, k.qkv_w, C, M, 2 * C, C, k.qkv_b, nullptr, d->qk, 2 * C, nullptr, 0, Tp, d->H, M, EPI_OP16};
+            GemmArgs g{d->xn, C, k.qkv_w, C, M, 2 * C, C, k.qkv_b, nullptr, d->qk, 2 * C, nullptr, 0, Tp, d->H, M, EPI_OP16_QK};
             TRY(mhmr_launch_gemm(g, dt, s));
             GemmArgs gv{d->xn, C, (const char*)k.qkv_w + (size_t)2 * C * C * esz, C, M, C, C, k.qkv_b + 2 * C, nullptr, d->vt, 0,
                         nullptr, 0, Tp, d->H, M, EPI_VT};
             TRY(mhmr_launch_gemm(gv, dt, s));
         }
-        TRY(mhmr_launch_attention(d->qk, d->vt, d->att, B, d->T, Tp, C, d->H, dt, s));
+        TRY(mhmr_launch_attention(d->qk, d->vt, d->att, B, d->T, Tp, C, d->H, dt, d->attn_flags, s));
         {
             GemmArgs g{d->att, C, k.proj_w, C, M, C, C, k.proj_b, k.ls1, d->resid, C, nullptr, 0, Tp, d->H, M, EPI_RESID};
             TRY(mhmr_launch_gemm(g, dt, s));

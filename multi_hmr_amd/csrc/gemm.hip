@@ -107,9 +107,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         __syncthreads();  // every wave is done reading the last K tile
         char* wl = smem + w * 16384;
         const int mb = m0 + 64 * wq_, nb = n0 + 64 * wp_;
-        constexpr bool OUT16 = (EPI == EPI_OP16 || EPI == EPI_OP16_GELU || EPI == EPI_OP16_RELU);
+        constexpr bool OUT16 = (EPI == EPI_OP16 || EPI == EPI_OP16_GELU || EPI == EPI_OP16_RELU || EPI == EPI_OP16_QK);
         if constexpr (OUT16) {
             // bias + activation + convert here (lane owns 4 consecutive n), LDS rows = 64 n x 2 B = 128 B
+            const float qscale = (EPI == EPI_OP16_QK && nb < (g.N >> 1)) ? MHMR_ATTN_QSCALE : 1.f;   // the wave's 64 columns are all Q or all K
 #pragma unroll
             for (int pi = 0; pi < 2; ++pi)
 #pragma unroll
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                             float v = acc[pi][qj][4 * rg + e] + bv[e];
                             if constexpr (EPI == EPI_OP16_GELU) v = gelu_fast(v);
                             if constexpr (EPI == EPI_OP16_RELU) v = fmaxf(v, 0.f);
+                            if constexpr (EPI == EPI_OP16_QK) v *= qscale;
                             o[e] = (T)v;
                         }
                         *(V4*)(wl + ml * 128 + (((nl >> 2) ^ ((ml & 7) << 1)) * 8)) = o;
@@ -227,6 +229,7 @@ int launch_dt(const GemmArgs& g, hipStream_t s) {
         MHMR_GEMM_CASE(EPI_PATCH)
         MHMR_GEMM_CASE(EPI_F32)
         MHMR_GEMM_CASE(EPI_VT)
+        MHMR_GEMM_CASE(EPI_OP16_QK)
         default:
             return MHMR_ERR_BAD_ARG;
     }
@@ -246,6 +249,7 @@ int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % BM || g.N % BN || g.K % BK) return MHMR_ERR_BAD_SHAPE;
     if (g.lda % 8 || g.ldw % 8) return MHMR_ERR_BAD_SHAPE;
     if (g.epi == EPI_VT && (g.Tp % BM || g.N % 64)) return MHMR_ERR_BAD_SHAPE;
+    if (g.epi == EPI_OP16_QK && g.N % 128) return MHMR_ERR_BAD_SHAPE;      // Q | K halves are whole 64-column blocks
     prof_begin(PROF_GEMM, s);
     int rc;
     if (!g_force_gemm128 && mhmr_gemm256_eligible(g)) {

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         // per quadrant, the wave's [32 Q-rows][64 P-cols] block is transposed through LDS so that global accesses are
         // whole contiguous row segments (a direct store from the MFMA layout camps on one memory channel).
         char* wl = smem + STAGE_OFF + w * 4096;
-        constexpr bool OUT16 = (EPI == EPI_OP16 || EPI == EPI_OP16_GELU || EPI == EPI_OP16_RELU || EPI == EPI_VT);
+        constexpr bool OUT16 = (EPI == EPI_OP16 || EPI == EPI_OP16_GELU || EPI == EPI_OP16_RELU || EPI == EPI_VT || EPI == EPI_OP16_QK);
         if constexpr (EPI == EPI_RESID) {
             // out32 += gamma * (acc + bias), in place.  8 passes (h, j, qs) of [16 rows][64 cols] fp32 per wave; a pass that
             // loads its residual lines only when it needs them pays one HBM round trip per pass (8 in series: 22-25 us per
@@ -261,6 +261,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                 const int pb = p0 + 128 * h + 64 * wp;      // first P index of the block (n for row-major, token for V^T)
                 const int qb = q0 + 128 * j + 32 * wq;      // first Q index (m for row-major, channel for V^T)
                 if constexpr (OUT16) {
+                    const float qscale = (EPI == EPI_OP16_QK && pb < (g.N >> 1)) ? MHMR_ATTN_QSCALE : 1.f;   // 64 columns: all Q or all K
 #pragma unroll
                     for (int ps = 0; ps < 4; ++ps) {
                         const int pc = 16 * ps + 4 * g4;    // lane owns P columns pc..pc+3 of Q rows 16*qs + l15
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                                 float v = acc[h][j][ps][qs][e];
                                 if constexpr (EPI == EPI_OP16_GELU) v = gelu_fast(v);
                                 if constexpr (EPI == EPI_OP16_RELU) v = fmaxf(v, 0.f);
+                                if constexpr (EPI == EPI_OP16_QK) v *= qscale;
                                 o[e] = (T)v;
                             }
                             *(V4*)(wl + qr * 128 + (((pos >> 2) ^ ((qr & 7) << 1)) * 8)) = o;
@@ -362,6 +364,7 @@ int launch256_dt(const GemmArgs& g, hipStream_t s) {
         MHMR_GEMM_CASE(EPI_PATCH)
         MHMR_GEMM_CASE(EPI_F32)
         MHMR_GEMM_CASE(EPI_VT)
+        MHMR_GEMM_CASE(EPI_OP16_QK)
         default:
             return MHMR_ERR_BAD_ARG;
     }

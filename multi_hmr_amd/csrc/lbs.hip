@@ -149,9 +149,16 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
         float tr[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) tr[a] = (Ki[a * 3] * lx + Ki[a * 3 + 1] * ly + Ki[a * 3 + 2] * 1.0f) * d;
-        float hc[3] = {sTw[c.center_joint][0] - sTw[0][0], sTw[c.center_joint][1] - sTw[0][1], sTw[c.center_joint][2] - sTw[0][2]};
+        // person_center joint given: recentre on it (smpl_layer.py:131-136); None (center_joint < 0): the pelvis is ADDED to the
+        // translation instead and nothing is recentred (smpl_layer.py:128-130), i.e. o = tr + pelvis
         float cc[3];
-        mat3_vec(R0, hc, cc);
+        if (c.center_joint >= 0) {
+            float hc[3] = {sTw[c.center_joint][0] - sTw[0][0], sTw[c.center_joint][1] - sTw[0][1], sTw[c.center_joint][2] - sTw[0][2]};
+            mat3_vec(R0, hc, cc);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) cc[a] = -sTw[0][a];
+        }
 #pragma unroll
         for (int e = 0; e < 9; ++e) sX[e] = R0[e];
 #pragma unroll

@@ -12,6 +12,7 @@ enum GemmEpilogue {
     EPI_PATCH = 4,      // out32[row(m)][n] = acc + bias + pos[1 + m % Np][n],  row(m) = (m / Np) * Tp + 1 + m % Np
     EPI_F32 = 5,        // out32[m][n] = acc (+ bias)
     EPI_VT = 6,         // vt[b][h][d][swap23(t)] = acc + bias               (V^T for the attention kernel)
+    EPI_OP16_QK = 7,    // out16[m][n] = (acc + bias) * (n < N/2 ? MHMR_ATTN_QSCALE : 1)   (Q | K projection, softmax scale folded into Q)
 };
 
 struct GemmArgs {

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import _lib, packing
+from . import _lib, packing, vit
 from .packing import roundup
 from .synthetic import SMPLX_JOINT_NAMES, VIT_CFG
 
@@ -232,6 +232,8 @@ class Model(nn.Module):
         super().__init__()
         if isinstance(img_size, (list, tuple)):
             img_size = img_size[0]
+        # clip_dist is stored as a 1-tuple exactly as the reference does (model.py:56): `if self.clip_dist:` (model.py:200) is then
+        # always true, so the reference clamps the distance to [0, 50] whatever the argument says -- and so does hph_decode_kernel
         self.img_size, self.nearness, self.clip_dist = img_size, nearness, (clip_dist,)
         self.xat_depth, self.xat_num_heads, self.num_betas = xat_depth, xat_num_heads, num_betas
         self.precision = kwargs.get("precision", os.environ.get("MHMR_PRECISION", "f16"))
@@ -256,55 +258,38 @@ class Model(nn.Module):
         self.x_attention_head = HPH(context_dim=self.embed_dim + self.camera_embed_dim, dim=1024, depth=xat_depth,
                                     heads=xat_num_heads, mlp_dim=1024, dim_head=32, at_token_res=img_size // PATCH,
                                     num_betas=num_betas, mean_params=_load_mean_params(kwargs.get("mean_params")))
-        self._packed = None      # (device, precision) -> tensors + descriptors
-        self._ws = {}            # batch size -> workspaces
+        self._packed = None                 # tensors + descriptors of the current (device, precision, parameters)
+        self._ws = vit.WorkspaceCache()     # the workspace of the most recent batch size
         for p in self.parameters():
             p.requires_grad_(False)
 
     # -------------------------------------------------------------------------------------------------- packing
     def load_state_dict(self, state_dict, strict=True, **kw):
-        self._packed = None
+        self.repack()
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
     def _apply(self, fn, *a, **k):
-        self._packed, self._ws = None, {}
+        self.repack()
         return super()._apply(fn, *a, **k)
 
     def repack(self):
-        """Call after mutating parameters in place (load_state_dict / .to() do it automatically)."""
-        self._packed, self._ws = None, {}
+        """Drop the packed weights AND the workspace whose descriptor points into them (call after mutating parameters in place;
+        load_state_dict / .to() do it automatically)."""
+        self._packed = None
+        self._ws.clear()
 
     def _pack(self, device):
-        dt_id, tdt = packing.OP_DTYPES[self.precision]
-        enc = self.backbone.encoder
-        C, H, L = enc.embed_dim, enc.num_heads, len(enc.blocks)
-        S, G = self.img_size, self.img_size // PATCH
-        N, T = G * G, G * G + 1
+        self._ws.clear()
+        P = vit.pack_encoder(self.backbone.encoder, self.img_size, self.precision, device)
+        dt_id, tdt = P["dt_id"], P["tdt"]
+        C, G, N = P["C"], P["G"], P["N"]
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         op = lambda t: t.detach().to(device=device, dtype=torch.float32).to(tdt).contiguous()
-        keep = []      # tensors referenced by raw pointers in the descriptors
+        keep = P["keep"]      # tensors referenced by raw pointers in the descriptors
 
         def k(t):
             keep.append(t)
             return t.data_ptr()
-
-        P = {"dt_id": dt_id, "tdt": tdt, "C": C, "H": H, "L": L, "G": G, "N": N, "T": T, "Tp": roundup(T, 128), "Kp": 640}
-        pos = torch.from_numpy(packing.interpolate_pos_embed(enc.pos_embed.detach().float().cpu().numpy(), G)).to(device)
-        cls_pos0 = f32(enc.cls_token.reshape(-1)) + pos[0]
-        pw = torch.zeros(C, P["Kp"], dtype=torch.float32, device=device)
-        pw[:, :588] = f32(enc.patch_embed.proj.weight).reshape(C, 588)
-        blocks = (_lib.VitBlock * L)()
-        for i, b in enumerate(enc.blocks):
-            blk = blocks[i]
-            blk.ln1_w, blk.ln1_b = k(f32(b.norm1.weight)), k(f32(b.norm1.bias))
-            blk.qkv_w, blk.qkv_b = k(op(b.attn.qkv.weight)), k(f32(b.attn.qkv.bias))
-            blk.proj_w, blk.proj_b, blk.ls1 = k(op(b.attn.proj.weight)), k(f32(b.attn.proj.bias)), k(f32(b.ls1.gamma))
-            blk.ln2_w, blk.ln2_b = k(f32(b.norm2.weight)), k(f32(b.norm2.bias))
-            blk.fc1_w, blk.fc1_b = k(op(b.mlp.fc1.weight)), k(f32(b.mlp.fc1.bias))
-            blk.fc2_w, blk.fc2_b, blk.ls2 = k(op(b.mlp.fc2.weight)), k(f32(b.mlp.fc2.bias)), k(f32(b.ls2.gamma))
-        P["vit"] = dict(blocks=blocks, patch_w=k(pw.to(tdt).contiguous()), patch_b=k(f32(enc.patch_embed.proj.bias)),
-                        cls_pos0=k(cls_pos0.contiguous()), pos=k(pos.contiguous()), norm_w=k(f32(enc.norm.weight)),
-                        norm_b=k(f32(enc.norm.bias)))
 
         # heads
         Cc = C + 99
@@ -351,37 +336,17 @@ class Model(nn.Module):
 
         # SMPL-X
         layer = self.smpl_layer[f"neutral_{nb}"]
-        P["lbs"] = packing.pack_smplx(self._smplx_data, nb, device, layer.person_center_idx if layer.person_center_idx is not None else 15)
+        P["lbs"] = packing.pack_smplx(self._smplx_data, nb, device, layer.person_center_idx if layer.person_center_idx is not None else -1)
         P["lbs_struct"] = packing.lbs_consts_struct(P["lbs"])
-        P["keep"] = keep
-        P["device"] = device
         self._packed = P
         return P
 
     def _workspace(self, P, B):
-        ws = self._ws.get(B)
-        if ws is not None:
-            return ws
-        dev, tdt = P["device"], P["tdt"]
-        C, N, Tp, H = P["C"], P["N"], P["Tp"], P["H"]
-        Mp = roundup(B * N, 128)
-        z = lambda *s, dtype=tdt: torch.zeros(*s, dtype=dtype, device=dev)
-        ws = dict(a_patch=z(Mp, P["Kp"]), resid=z(B * Tp, C, dtype=torch.float32), xn=z(B * Tp, C), qk=z(B * Tp, 2 * C),
-                  vt=z(B * H * 64, Tp), att=z(B * Tp, C), hid=z(B * Tp, 4 * C), feat32=z(B * N, C, dtype=torch.float32),
-                  ctx16=z(Mp, P["Kc"]), zK=z(B * N, 99, dtype=torch.float32), scores=z(B * N, dtype=torch.float32),
-                  counts=z(B, dtype=torch.int32), kv=z(Mp, P["hph"]["n_kv"], dtype=torch.float32))
-        v = P["vit"]
-        d = _lib.VitDesc()
-        d.dtype, d.B, d.S, d.C, d.H, d.L = P["dt_id"], B, self.img_size, C, H, P["L"]
-        d.G, d.N, d.T, d.Tp, d.Kp = P["G"], N, P["T"], Tp, P["Kp"]
-        d.patch_w, d.patch_b, d.cls_pos0, d.pos = v["patch_w"], v["patch_b"], v["cls_pos0"], v["pos"]
-        d.blocks = C_cast_blocks(v["blocks"])
-        d.norm_w, d.norm_b = v["norm_w"], v["norm_b"]
-        for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid"):
-            setattr(d, n, ws[n].data_ptr())
-        ws["vit_desc"] = d
-        self._ws[B] = ws
-        return ws
+        def extra(P, B, z):
+            Mp = roundup(B * P["N"], 128)
+            return dict(ctx16=z(Mp, P["Kc"]), zK=z(B * P["N"], 99, dtype=torch.float32), scores=z(B * P["N"], dtype=torch.float32),
+                        counts=z(B, dtype=torch.int32), kv=z(Mp, P["hph"]["n_kv"], dtype=torch.float32))
+        return self._ws.get(P, B, extra)
 
     # -------------------------------------------------------------------------------------------------- forward
     def backbone_features(self, x):
@@ -518,7 +483,3 @@ class Model(nn.Module):
         return [{"scores": scores_det[i], "loc": loc[i], "transl": transl[i], "transl_pelvis": out["transl_pelvis"][i],
                  "rotvec": rotvec[i], "expression": expression[i], "shape": shape[i], "v3d": v3d[i], "j3d": j3d[i], "j2d": j2d[i]}
                 for i in range(Pn)]
-
-
-def C_cast_blocks(arr):
-    return C.cast(arr, C.POINTER(_lib.VitBlock))

@@ -53,7 +53,7 @@ def interpolate_pos_embed(pos_embed: np.ndarray, G: int, offset: float = 0.1) ->
 
 
 # ---------------------------------------------------------------------------------------------- SMPL-X
-def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) -> dict:
+def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) -> dict:  # person_center_idx < 0: no recentring
     """SMPL-X arrays (keys of SMPLX_NEUTRAL.npz) -> mhmr_lbs_consts tensors.
 
     * blend basis rows = [posedirs (486) | shapedirs[:, :, :nb] | shapedirs[:, :, 300:310] | 0-pad], scaled by 2^10 into the f16

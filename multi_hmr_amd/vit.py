@@ -1,0 +1,95 @@
+"""Shared host glue for the DINOv2 ViT backbone kernels: weight packing and per-batch workspaces / descriptors.
+
+Used by ``model.Model`` (reference model.py:30-349) and ``anny_model.Multi_HMR`` (reference multi_hmr_anny/multi_hmr.py); both run
+``mhmr_vit_forward`` (include/mhmr.h) on the result.  Nothing here is on the per-image path except ``workspace()``'s dictionary
+lookup.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib, packing
+from .packing import roundup
+
+PATCH = 14
+
+
+def pack_encoder(enc, img_size: int, precision: str, device) -> dict:
+    """DINOv2 encoder parameters (key names of torch.hub dinov2_vit*14) -> device tensors in the kernels' layouts.
+
+    16-bit [N, K] linears (K contiguous = MFMA operand order), fp32 biases / LayerNorm / LayerScale, the pos-embed bicubically
+    interpolated to the G x G grid on the host (``packing.interpolate_pos_embed``), the patch-embed weight flattened (c, py, px)
+    and zero-padded to Kp = 640.  The returned dict owns every tensor the block descriptors point at (``keep``)."""
+    dt_id, tdt = packing.OP_DTYPES[precision]
+    Cd, H, L = enc.embed_dim, enc.num_heads, len(enc.blocks)
+    G = img_size // PATCH
+    N, T = G * G, G * G + 1
+    f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+    op = lambda t: t.detach().to(device=device, dtype=torch.float32).to(tdt).contiguous()
+    keep = []
+
+    def k(t):
+        keep.append(t)
+        return t.data_ptr()
+
+    P = {"dt_id": dt_id, "tdt": tdt, "C": Cd, "H": H, "L": L, "G": G, "N": N, "T": T, "Tp": roundup(T, 128), "Kp": 640,
+         "S": img_size, "device": device}
+    pos = torch.from_numpy(packing.interpolate_pos_embed(enc.pos_embed.detach().float().cpu().numpy(), G)).to(device)
+    cls_pos0 = f32(enc.cls_token.reshape(-1)) + pos[0]
+    pw = torch.zeros(Cd, P["Kp"], dtype=torch.float32, device=device)
+    pw[:, :588] = f32(enc.patch_embed.proj.weight).reshape(Cd, 588)
+    blocks = (_lib.VitBlock * L)()
+    for i, b in enumerate(enc.blocks):
+        blk = blocks[i]
+        blk.ln1_w, blk.ln1_b = k(f32(b.norm1.weight)), k(f32(b.norm1.bias))
+        blk.qkv_w, blk.qkv_b = k(op(b.attn.qkv.weight)), k(f32(b.attn.qkv.bias))
+        blk.proj_w, blk.proj_b, blk.ls1 = k(op(b.attn.proj.weight)), k(f32(b.attn.proj.bias)), k(f32(b.ls1.gamma))
+        blk.ln2_w, blk.ln2_b = k(f32(b.norm2.weight)), k(f32(b.norm2.bias))
+        blk.fc1_w, blk.fc1_b = k(op(b.mlp.fc1.weight)), k(f32(b.mlp.fc1.bias))
+        blk.fc2_w, blk.fc2_b, blk.ls2 = k(op(b.mlp.fc2.weight)), k(f32(b.mlp.fc2.bias)), k(f32(b.ls2.gamma))
+    P["vit"] = dict(blocks=blocks, patch_w=k(pw.to(tdt).contiguous()), patch_b=k(f32(enc.patch_embed.proj.bias)),
+                    cls_pos0=k(cls_pos0.contiguous()), pos=k(pos.contiguous()), norm_w=k(f32(enc.norm.weight)),
+                    norm_b=k(f32(enc.norm.bias)))
+    P["keep"] = keep
+    return P
+
+
+class WorkspaceCache:
+    """ONE cached workspace: the one of the most recent (pack, batch size).  A different batch size or a repack (load_state_dict,
+    .to(), repack()) replaces it, so a descriptor never outlives the tensors its raw pointers refer to and a model does not pin a
+    multi-GB workspace per batch size it has ever seen."""
+
+    def __init__(self):
+        self._key, self._ws = None, None
+
+    def clear(self):
+        self._key, self._ws = None, None
+
+    def get(self, P: dict, B: int, extra):
+        """extra(P, B, z) -> dict of additional workspace tensors (z = zero-tensor factory in the operand dtype)."""
+        key = (id(P), B)
+        if self._key == key:
+            return self._ws
+        self._ws = None                                   # free the old one before allocating
+        dev, tdt = P["device"], P["tdt"]
+        Cd, N, Tp, H = P["C"], P["N"], P["Tp"], P["H"]
+        Mp = roundup(B * N, 128)
+        z = lambda *s, dtype=tdt: torch.zeros(*s, dtype=dtype, device=dev)
+        ws = dict(a_patch=z(Mp, P["Kp"]), resid=z(B * Tp, Cd, dtype=torch.float32), xn=z(B * Tp, Cd), qk=z(B * Tp, 2 * Cd),
+                  vt=z(B * H * 64, Tp), att=z(B * Tp, Cd), hid=z(B * Tp, 4 * Cd), feat32=z(B * N, Cd, dtype=torch.float32),
+                  attn_flags=z(_lib.lib().mhmr_attention_flag_count(B, Tp, H), dtype=torch.int32))
+        ws.update(extra(P, B, z))
+        v = P["vit"]
+        d = _lib.VitDesc()
+        d.dtype, d.B, d.S, d.C, d.H, d.L = P["dt_id"], B, P["S"], Cd, H, P["L"]
+        d.G, d.N, d.T, d.Tp, d.Kp = P["G"], N, P["T"], Tp, P["Kp"]
+        d.patch_w, d.patch_b, d.cls_pos0, d.pos = v["patch_w"], v["patch_b"], v["cls_pos0"], v["pos"]
+        d.blocks = C.cast(v["blocks"], C.POINTER(_lib.VitBlock))
+        d.norm_w, d.norm_b = v["norm_w"], v["norm_b"]
+        for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid", "attn_flags"):
+            setattr(d, n, ws[n].data_ptr())
+        ws["vit_desc"] = d
+        self._key, self._ws = key, ws
+        return ws

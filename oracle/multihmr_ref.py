@@ -201,11 +201,15 @@ def smpl_layer_forward(bm, pose, shape, loc, dist, K, expression, person_center_
     j3d = (R.unsqueeze(1) @ (j3d - pelvis).unsqueeze(-1)).squeeze(-1)
     verts = (R.unsqueeze(1) @ (verts - pelvis).unsqueeze(-1)).squeeze(-1)
     transl = inverse_perspective_projection(loc.unsqueeze(1), K, dist.unsqueeze(1))[:, 0]
-    center = j3d[:, [person_center_idx]]
-    verts = verts - center
-    j3d = j3d - center
-    j3d_cam = j3d + transl.unsqueeze(1)
-    verts_cam = verts + transl.unsqueeze(1)
+    transl_up = transl.clone()
+    if person_center_idx is None:                 # smpl_layer.py:128-130: the pelvis is added to the translation, nothing recentred
+        transl_up = transl_up + pelvis[:, 0]
+    else:                                         # smpl_layer.py:131-136
+        center = j3d[:, [person_center_idx]]
+        verts = verts - center
+        j3d = j3d - center
+    j3d_cam = j3d + transl_up.unsqueeze(1)
+    verts_cam = verts + transl_up.unsqueeze(1)
     return {"v3d": verts_cam, "j3d": j3d_cam, "j2d": perspective_projection(j3d_cam, K),
             "v2d": perspective_projection(verts_cam, K), "transl": transl, "transl_pelvis": j3d_cam[:, [0]]}
 

@@ -29,6 +29,12 @@ CASES = {
     "vitb_224_train": dict(backbone="dinov2_vitb14", img_size=224, depth_override=4, batch=2, persons=[1, 2], seed=4),
     "vits_448_infer": dict(backbone="dinov2_vits14", img_size=448, depth_override=2, batch=3, persons=None, seed=3,
                            nms_kernel_size=3, target_detections=5),
+    # BASELINE.json configurations at their full resolution and depth (one or two images: the reference on CPU needs minutes).
+    # ``vstride`` keeps the files small: v3d / v2d are stored for every vstride-th vertex, everything else in full.
+    "vits_672_full": dict(backbone="dinov2_vits14", img_size=672, depth_override=None, batch=2, persons=[8, 5], seed=21, vstride=4),
+    "vitl_672_full": dict(backbone="dinov2_vitl14", img_size=672, depth_override=None, batch=1, persons=[8], seed=22, vstride=4),
+    "vitl_896_full": dict(backbone="dinov2_vitl14", img_size=896, depth_override=None, batch=1, persons=[8], seed=23, vstride=4),
+    "vitl_1288_full": dict(backbone="dinov2_vitl14", img_size=1288, depth_override=None, batch=1, persons=[20], seed=24, vstride=8),
 }
 
 
@@ -82,8 +88,9 @@ def main():
                 out["backbone"] = z[:, :: max(1, z.shape[1] // 64)].numpy()      # token subsample keeps files small
                 if idx is not None:
                     res = model(x, idx=idx, K=K, is_training=True)
+                    vs = cfg.get("vstride", 1)
                     for k, v in res.items():
-                        out[k] = v.numpy()
+                        out[k] = v[:, ::vs].numpy() if (vs > 1 and k in ("v3d", "v2d")) else v.numpy()
                 else:
                     # choose the classifier bias + threshold so that a handful of tokens are detected, with the
                     # threshold centred in the widest score gap (no detection is within rounding of it)

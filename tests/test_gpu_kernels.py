@@ -63,6 +63,10 @@ def test_gemm_epilogues(L, name, dt, tdt, tol, M, N, K):
     assert maxrel(out.float(), torch.nn.functional.gelu(ref)) < tol
     call(out, N, _lib.EPI_OP16_RELU)
     assert maxrel(out.float(), torch.relu(ref)) < tol
+    call(out, N, _lib.EPI_OP16_QK)             # Q | K projection: the first N/2 columns carry the softmax scale in the exp2 domain
+    colscale = torch.ones(N, device=dev())
+    colscale[: N // 2] = _lib.ATTN_QSCALE
+    assert maxrel(out.float(), ref * colscale) < tol
     o32 = torch.zeros(M, N, device=dev())
     call(o32, N, _lib.EPI_F32)
     assert maxrel(o32, ref) < 2e-5, ("f32", maxrel(o32, ref))
@@ -129,27 +133,99 @@ def test_gemm_patch_and_vt_layouts(L, name, dt, tdt, tol):
 
 
 # ------------------------------------------------------------------------------------------------------ attention
-@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
-@pytest.mark.parametrize("B,H,T", [(2, 3, 200), (1, 2, 256), (1, 1, 65), (2, 6, 257)])
-def test_attention(L, name, dt, tdt, tol, B, H, T):
+def _attn_inputs(B, H, T, tdt, seed, qscale=1.0):
+    """q is handed over PRE-SCALED (include/mhmr.h: the Q half of qk holds q * MHMR_ATTN_QSCALE, scores are in the exp2 domain)."""
     C, Tp = H * 64, packing.roundup(T, 128)
-    g = torch.Generator(device="cpu").manual_seed(T)
-    q = torch.randn(B, Tp, H, 64, generator=g).to(dev()).to(tdt)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    q = (torch.randn(B, Tp, H, 64, generator=g) * _lib.ATTN_QSCALE * qscale).to(dev()).to(tdt)
     k = torch.randn(B, Tp, H, 64, generator=g).to(dev()).to(tdt)
     v = torch.randn(B, Tp, H, 64, generator=g).to(dev()).to(tdt)
-    k[0, min(T - 1, 70), 0] *= 6.0          # a spiked key forces the running-max rescale branch late in the loop
+    return q, k, v, C, Tp
+
+
+def _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=None, variant=0):
     qk = torch.cat([q.reshape(B * Tp, C), k.reshape(B * Tp, C)], dim=1).contiguous()
     vt = torch.zeros(B, H, 64, Tp, dtype=tdt, device=dev())
     vt[..., swap23(torch.arange(Tp, device=dev()))] = v.permute(0, 2, 3, 1)
     out = torch.zeros(B * Tp, C, dtype=tdt, device=dev())
-    _lib.check(L.mhmr_attention16(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), B, T, Tp, C, H, dt, stream()), "attention")
-    qf, kf, vf = [t.double().permute(0, 2, 1, 3) for t in (q, k, v)]
-    att = torch.softmax(qf[:, :, :T] @ kf[:, :, :T].transpose(-1, -2) * 0.125, dim=-1) @ vf[:, :, :T]
-    ref = att.permute(0, 2, 1, 3).reshape(B, T, C)
-    got = out.view(B, Tp, C)[:, :T].double()
-    err = float((got - ref).abs().max())
+    if thr is None:
+        _lib.check(L.mhmr_attention16(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), B, T, Tp, C, H, dt, stream()), "attention")
+    else:
+        flags = torch.full((L.mhmr_attention_flag_count(B, Tp, H),), 7, dtype=torch.int32, device=dev())   # (the call zeroes them)
+        _lib.check(L.mhmr_attention16_ex(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), B, T, Tp, C, H, dt, thr, variant,
+                                         flags.data_ptr() if variant == 0 else None, stream()), "attention_ex")
+        _attn_run.last_flags = flags
+    return out.view(B, Tp, C)
+
+
+def _attn_ref(q, k, v, T, rows=None):
+    """fp64 softmax_2(q k^T) v on the (already rounded) operands; rows = query rows to evaluate (None = all T)."""
+    qf, kf, vf = [t.double().permute(0, 2, 1, 3) for t in (q, k, v)]            # [B,H,t,64]
+    qs = qf[:, :, :T] if rows is None else qf[:, :, rows]
+    att = torch.softmax(qs @ kf[:, :, :T].transpose(-1, -2) * math.log(2.0), dim=-1) @ vf[:, :, :T]
+    return att.permute(0, 2, 1, 3).reshape(att.shape[0], att.shape[2], -1)       # [B,rows,C]
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("B,H,T", [(2, 3, 200), (1, 2, 256), (1, 1, 65), (2, 6, 257)])
+def test_attention(L, name, dt, tdt, tol, B, H, T):
+    q, k, v, C, Tp = _attn_inputs(B, H, T, tdt, T)
+    k[0, min(T - 1, 70), 0] *= 6.0          # a spiked key moves the row maximum late in the loop
+    got = _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt)[:, :T].double()
+    err = float((got - _attn_ref(q, k, v, T)).abs().max())
     assert err < (4e-3 if name == "f16" else 3e-2), err
-    assert torch.isfinite(out.float()).all()
+    assert torch.isfinite(got).all()
+
+
+@pytest.mark.parametrize("T", [2305, 4097, 8465])        # 672^2, 896^2, 1288^2: 37 / 65 / 133 key tiles, the last one masked
+def test_attention_full_length_against_fp64(L, T):
+    """BASELINE sequence lengths, f16 operands, against fp64 on sampled query rows (first / last rows, tile and workgroup
+    boundaries, random rows); absolute error of an output that is an average of N(0,1) values."""
+    B, H = 1, 2
+    q, k, v, C, Tp = _attn_inputs(B, H, T, torch.float16, T)
+    got = _attn_run(L, q, k, v, B, H, T, C, Tp, _lib.DT_F16, torch.float16)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    rows = torch.cat([torch.tensor([0, 1, 31, 32, 63, 64, 127, 128, T - 130, T - 129, T - 65, T - 64, T - 2, T - 1]),
+                      torch.randint(0, T, (50,), generator=g)]).unique().to(dev())
+    ref = _attn_ref(q, k, v, T, rows)
+    err = float((got[:, rows].double() - ref).abs().max())
+    scale = float(ref.abs().max())
+    assert err < 1e-3 * max(scale, 0.05) + 2e-4, (err, scale)        # f16 output rounding of values ~0.05-0.2: ~1e-4
+    assert torch.isfinite(got[:, :T].float()).all()
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+def test_attention_reference_level_branches_are_exact(L, name, dt, tdt, tol):
+    """The kernel subtracts a per-query reference level inside the matrix pipe; it is the exact row maximum of key tile 0 and
+    moves again only when exp2(score - level) would leave the 16-bit range (a lane's tile sum > 2^15).  Inputs that FORCE every
+    branch (cdna guide: a rare data-dependent branch needs its own test): keys whose score beats the level by +20 ... +60 late in
+    the loop (rescale with score recomputation), a row whose first tiles lie far BELOW every later key, rows that never move.
+    The shipped limit (2^15), "rescale nearly every tile" (2^0) and an intermediate limit must agree to one output ulp, and all
+    kernel forms must match an fp64 reference of the FULL tensor."""
+    B, H, T = 2, 2, 900
+    q, k, v, C, Tp = _attn_inputs(B, H, T, tdt, 5, qscale=3.0)
+    kk = k.float()
+    qq = q.float()
+    # late spikes: keys in tiles 10, 5 and 1 aligned with query rows of head 0 -> scores +50 / +25 / +60 (exp2 domain)
+    for (row, key, target) in [(5, 700, 50.0), (130, 333, 25.0), (899, 64, 60.0), (64, 899, 20.0)]:
+        d = qq[0, row, 0]
+        kk[0, key, 0] = d / d.norm() ** 2 * target
+    # a query row whose every score is very negative in the first tiles: all keys 0..191 of image 1 / head 1 point against it
+    d = qq[1, 7, 1]
+    kk[1, :192, 1] = -d / d.norm() ** 2 * 40.0 + 0.01 * kk[1, :192, 1]
+    k = kk.to(tdt)
+    ref = _attn_ref(q, k, v, T)
+    outs = {lim: _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=lim)[:, :T].double() for lim in (15.0, 0.0, 6.0)}
+    bound = 4e-3 if name == "f16" else 3e-2
+    for lim, got in outs.items():
+        assert torch.isfinite(got).all(), lim
+        err = float((got - ref).abs().max())
+        assert err < bound, (lim, err)
+    for lim in (15.0, 6.0):      # same function, different rounding order: at most one output ulp apart (|O| <= ~4)
+        assert float((outs[lim] - outs[0.0]).abs().max()) <= (2.0 ** -8 if name == "f16" else 2.0 ** -5), lim
+    for variant in (1, 2):       # the A/B forms compute the same function
+        got = _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=15.0, variant=variant)[:, :T].double()
+        assert float((got - ref).abs().max()) < bound, variant
 
 
 # ------------------------------------------------------------------------------------------------------ norms, patchify
@@ -238,12 +314,14 @@ def test_camera_embed(L):
 
 
 # ------------------------------------------------------------------------------------------------------ LBS
-@pytest.mark.parametrize("P", [1, 5, 70, 300])          # 300: one full 256-person slab + a 3-wave remainder workgroup
-def test_lbs_against_oracle(L, smplx_data, P):
+@pytest.mark.parametrize("P,center", [(1, 15), (5, 15), (70, 15), (300, 15), (37, None), (37, 0)])   # 300: one full 256-person slab + a remainder
+def test_lbs_against_oracle(L, smplx_data, P, center):
+    """center: person_center joint (15 = 'head', the released checkpoints; 0 = 'pelvis'; None = vanilla SMPL-X placement,
+    reference blocks/smpl_layer.py:128-136)."""
     import ctypes as C
     from oracle import smplx_ref
     from oracle.multihmr_ref import smpl_layer_forward
-    pk = packing.pack_smplx(smplx_data, 10, dev())
+    pk = packing.pack_smplx(smplx_data, 10, dev(), -1 if center is None else center)
     cs = packing.lbs_consts_struct(pk)
     g = torch.Generator(device="cpu").manual_seed(P)
     pose = 0.35 * torch.randn(P, 53, 3, generator=g)
@@ -255,7 +333,7 @@ def test_lbs_against_oracle(L, smplx_data, P):
     K[:, 0, 2] += torch.arange(B) * 4.0
     loc = 448 * torch.rand(P, 2, generator=g)
     dist = 2 + 6 * torch.rand(P, 1, generator=g)
-    ref = smpl_layer_forward(smplx_ref.SMPLX(smplx_data, num_betas=10), pose, shape, loc, dist, K[det_b], expr)
+    ref = smpl_layer_forward(smplx_ref.SMPLX(smplx_data, num_betas=10), pose, shape, loc, dist, K[det_b], expr, person_center_idx=center)
     d = lambda t, dt=torch.float32: t.to(device=dev(), dtype=dt).contiguous()
     V = pk["V"]
     f = lambda *s: torch.zeros(*s, device=dev())

@@ -111,3 +111,24 @@ def test_forward_model_wrapper_and_autocast(smplx_data, mean_params):
     b = model(x.cuda(), K=K.cuda(), det_thresh=0.5, nms_kernel_size=3)
     assert len(a) == len(b) and len(a) > 0
     assert all(torch.equal(p["v3d"], q["v3d"]) for p, q in zip(a, b))
+
+
+def test_load_state_dict_after_a_forward_repacks_everything(smplx_data, mean_params):
+    """Regression (round-1 advisor finding): the cached workspace holds a descriptor with raw pointers into the packed weights; a
+    forward, then load_state_dict(other weights), then a forward at the SAME batch size must run entirely on the new weights."""
+    cfg = make_golden.CASES["vits_224_train"]
+    x, K, idx = make_golden.case_inputs(cfg)
+    xc, Kc, ic = x.cuda(), K.cuda(), tuple(i.cuda() for i in idx)
+    sd_a = make_golden.case_state_dict(cfg)
+    sd_b = synthetic.make_state_dict(cfg["backbone"], cfg["img_size"], seed=77, depth_override=cfg["depth_override"])
+    m = build(cfg, smplx_data, mean_params, "f16", sd_a)
+    out_a = m(xc, idx=ic, K=Kc, is_training=True)
+    m.load_state_dict(sd_b, strict=True)
+    out_b = m(xc, idx=ic, K=Kc, is_training=True)
+    fresh = build(cfg, smplx_data, mean_params, "f16", sd_b)(xc, idx=ic, K=Kc, is_training=True)
+    for k in ("scores", "v3d", "rotmat", "shape", "transl"):
+        assert torch.equal(out_b[k], fresh[k]), k
+    assert not torch.equal(out_a["v3d"], out_b["v3d"])
+    # a different batch size afterwards replaces the workspace (one is cached, not one per size)
+    out_1 = m(xc[:1], idx=tuple(i[ic[0] == 0] for i in ic), K=Kc[:1], is_training=True)
+    assert float((out_1["v3d"] - fresh["v3d"][ic[0] == 0]).abs().max()) < 1e-5

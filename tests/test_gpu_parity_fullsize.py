@@ -1,0 +1,76 @@
+"""-m gpu: the north-star parity contract AT BASELINE.json's sizes.  The golden vectors are the outputs of the reference's own
+model.py run verbatim on CPU fp32 (tests/golden/make_golden.py, cases *_full: full depth, full resolution, one or two images):
+
+  vits_672_full   multiHMR_672_S   672^2,  T = 2305, ViT-S/14 12 blocks, 8 + 5 persons        (config 2)
+  vitl_672_full   multiHMR_672_L   672^2,  T = 2305, ViT-L/14 24 blocks, 8 persons            (config 3)
+  vitl_896_full   multiHMR_896_L   896^2,  T = 4097, ViT-L/14 24 blocks, 8 persons            (config 4, the benchmark)
+  vitl_1288_full  multiHMR_1288_L  1288^2, T = 8465, ViT-L/14 24 blocks, 20 persons           (config 5)
+
+Every tensor the north star names (scores, SMPL-X parameters, vertices, and what derives from them) must be within 1e-3 relative
+L2 of the reference with the product precision (f16 MFMA operands, the precision bench.py reports).  The measured values are
+also written to gpurun_out/parity_fullsize.json (pytest -q hides prints); bf16 operands are measured beside, held to 2e-2."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import make_golden  # noqa: E402
+from multi_hmr_amd import Model  # noqa: E402
+from oracle import roma_ref  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+REPORT = os.path.join(ROOT, "gpurun_out", "parity_fullsize.json")
+TOL = {"f16": 1e-3, "bf16": 2e-2}
+CHECKED = ["scores", "offset", "loc", "dist", "dist_postprocessed", "shape", "expression", "rotmat", "transl", "transl_pelvis",
+           "v3d", "j3d", "j2d", "v2d"]
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def _report(name, precision, entry):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    data = {}
+    if os.path.isfile(REPORT):
+        with open(REPORT) as f:
+            data = json.load(f)
+    data[f"{name}/{precision}"] = entry
+    with open(REPORT, "w") as f:
+        json.dump(data, f, indent=1, sort_keys=True)
+
+
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+@pytest.mark.parametrize("name", ["vits_672_full", "vitl_672_full", "vitl_896_full", "vitl_1288_full"])
+def test_full_size_forward_matches_reference_golden(name, precision, smplx_data, mean_params):
+    cfg = make_golden.CASES[name]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    vs = cfg.get("vstride", 1)
+    model = Model(backbone=cfg["backbone"], img_size=cfg["img_size"], smplx_data=smplx_data, mean_params=mean_params, precision=precision)
+    model.load_state_dict(make_golden.case_state_dict(cfg), strict=True)
+    model = model.to("cuda:0").eval()
+    x, K, idx = make_golden.case_inputs(cfg)
+    z = model.backbone_features(x.cuda()).cpu()
+    e_bb = rel(z[:, :: max(1, z.shape[1] // 64)].numpy(), gold["backbone"])
+    out = model(x.cuda(), idx=tuple(i.cuda() for i in idx), K=K.cuda(), is_training=True)
+    got = {k: out[k].cpu() for k in CHECKED + ["rotvec"]}
+    for k in ("v3d", "v2d"):
+        got[k] = got[k][:, ::vs]
+    errs = {k: rel(got[k].numpy(), gold[k]) for k in CHECKED}
+    errs["rotvec"] = rel(roma_ref.rotvec_to_rotmat(got["rotvec"]).numpy(), roma_ref.rotvec_to_rotmat(torch.from_numpy(gold["rotvec"])).numpy())
+    vmax_mm = 1e3 * float(np.abs(got["v3d"].numpy() - gold["v3d"]).max())
+    finite = all(bool(torch.isfinite(v).all()) for v in got.values())
+    _report(name, precision, {"tolerance": TOL[precision], "backbone_rel_l2": e_bb, "max_vertex_error_mm": vmax_mm,
+                              "worst_rel_l2": max(errs.values()), "rel_l2": errs, "finite": finite,
+                              "tokens": int(cfg["img_size"] // 14) ** 2 + 1, "persons": int(sum(cfg["persons"]))})
+    print(f"\n[parity {name} {precision}] backbone {e_bb:.2e}; max vertex error {vmax_mm:.3f} mm; " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
+    assert finite
+    for k, v in errs.items():
+        assert v < TOL[precision], (k, v)
+    assert e_bb < 2 * TOL[precision], e_bb            # not a north-star output; informational bound

@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--img", type=int, default=896)
     ap.add_argument("--tp", type=int, default=0, help="override the padded token count per image (GEMM rows = batch * tp)")
+    ap.add_argument("--variants", default="0", help="attention kernel forms to time (comma separated, csrc/attention.hip)")
+    ap.add_argument("--thr", type=float, default=15.0, help="attention reference-level limit (log2)")
     a = ap.parse_args()
     L = _lib.lib()
     dt, tdt = (_lib.DT_F16, torch.float16) if a.dtype == "f16" else (_lib.DT_BF16, torch.bfloat16)
@@ -58,9 +60,14 @@ def main():
             print(f"gemm {name:18s} M={M} N={N} K={K}: {ms:8.4f} ms  {2.0 * B * T * N * K / ms / 1e9:8.1f} TFLOP/s (alg)  {2.0 * M * N * K / ms / 1e9:8.1f} (padded)")
     if a.only in ("", "attn"):
         qk, vt, out = rnd(M, 2 * C), rnd(B * H * 64, Tp), torch.zeros(M, C, dtype=tdt, device=dev)
-        fn = lambda: _lib.check(L.mhmr_attention16(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), B, T, Tp, C, H, dt, st), "attn")
-        ms = timeit(fn, a.iters)
-        print(f"attention B={B} H={H} T={T}: {ms:8.4f} ms  {4.0 * B * H * T * T * 64 / ms / 1e9:8.1f} TFLOP/s (alg)")
+        qk[:, :C] = (qk[:, :C].float() * _lib.ATTN_QSCALE).to(tdt)          # the Q half arrives pre-scaled (MHMR_EPI_OP16_QK)
+        flags = torch.zeros(L.mhmr_attention_flag_count(B, Tp, H), dtype=torch.int32, device=dev)
+        for rnd_ in range(2):                                                # two interleaved rounds: within-process A/B
+            for var in [int(v) for v in a.variants.split(",")]:
+                fn = lambda: _lib.check(L.mhmr_attention16_ex(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), B, T, Tp, C, H, dt, a.thr,
+                                                              var, flags.data_ptr() if var == 0 else None, st), "attn")
+                ms = timeit(fn, a.iters)
+                print(f"attention variant {var} B={B} H={H} T={T} {a.dtype}: {ms:8.4f} ms  {4.0 * B * H * T * T * 64 / ms / 1e9:8.1f} TFLOP/s (alg)", flush=True)
     if a.only in ("", "ln"):
         x, w, b = torch.randn(M, C, device=dev), torch.randn(C, device=dev), torch.randn(C, device=dev)
         o = torch.zeros(M, C, dtype=tdt, device=dev)

@@ -30,6 +30,13 @@ __global__ void k(float* out, long long* cyc, float a, float b) {
             if (OP == 11) asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(v[i]) : "v"(b));
             if (OP == 12) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*(double*)&v[i & 6]) : "v"(*(double*)&v[(i + 2) & 6]));
             if (OP == 13) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(v[i]) : "v"(b));
+            if (OP == 14) asm volatile("v_mov_b32 %0, %1" : "+v"(v[i]) : "v"(b));
+            if (OP == 15) asm volatile("v_pk_mov_b32 %0, %1, %1" : "+v"(*(double*)&v[i & 6]) : "v"(*(double*)&v[(i + 2) & 6]));
+            if (OP == 16) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(*(double*)&v[i & 6]) : "v"(*(double*)&v[(i + 2) & 6]));
+            if (OP == 17) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(v[i]) : "v"(b));
+            if (OP == 18) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(*(double*)&v[i & 6]) : "v"(*(double*)&v[(i + 2) & 6]));
+            if (OP == 19) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[i]) : "v"(b));
+            if (OP == 20) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
         }
     }
     long long t1 = clock64();
@@ -60,6 +67,8 @@ int main() {
         run<0>("v_fma_f32", nw); run<3>("v_add_f32", nw); run<10>("v_mul_f32", nw); run<13>("v_sub_f32", nw); run<1>("v_exp_f32", nw);
         run<2>("v_exp_f16", nw); run<9>("v_rcp_f32", nw); run<4>("v_max3_f32", nw); run<5>("v_cvt_pk_bf16_f32", nw); run<11>("v_cvt_pkrtz_f16_f32", nw);
         run<6>("v_dot2_f32_bf16", nw); run<7>("v_dot2_f32_f16", nw); run<8>("v_ldexp_f32", nw); run<12>("v_pk_mul_f32", nw);
+        run<14>("v_mov_b32", nw); run<15>("v_pk_mov_b32", nw); run<16>("v_pk_add_f32", nw); run<17>("v_cvt_pk_f16_f32", nw); run<18>("v_pk_fma_f32", nw);
+        run<19>("v_max_f32", nw); run<20>("v_fmac_f32", nw);
     }
     return 0;
 }
