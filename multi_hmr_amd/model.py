@@ -188,8 +188,8 @@ class HPH(_Holder):
 class _BodyModel:
     """What callers read from ``smpl_layer[...].bm_x`` (demo.py:310: ``.faces``)."""
 
-    def __init__(self, faces):
-        self.faces = faces
+    def __init__(self, faces, num_vertices):
+        self.faces, self.num_vertices = faces, num_vertices
 
 
 class SMPL_Layer(_Holder):
@@ -202,7 +202,7 @@ class SMPL_Layer(_Holder):
         self.joint_names = list(SMPLX_JOINT_NAMES)
         self.person_center = person_center
         self.person_center_idx = self.joint_names.index(person_center) if person_center is not None else None
-        self.bm_x = _BodyModel(np.asarray(data["f"], dtype=np.int64))
+        self.bm_x = _BodyModel(np.asarray(data["f"], dtype=np.int64), int(np.asarray(data["v_template"]).shape[0]))
 
 
 def _load_smplx_data(explicit):
@@ -371,11 +371,15 @@ class Model(nn.Module):
     @torch.no_grad()
     def forward(self, x, idx=None, det_thresh=0.3, nms_kernel_size=3, K=None, is_training=False, *args, **kwargs):
         """Same contract as the reference ``Model.forward`` (model.py:205-349): inference -> list of per-person dicts
-        (empty list if nobody is detected); ``is_training=True`` (needs ``idx``) -> dict of batched tensors."""
+        (empty list if nobody is detected); ``is_training=True`` (needs ``idx``) -> dict of batched tensors.
+        Extension used by ``distributed.forward_sharded``: ``return_image_index=True`` (inference only) -> (persons, image id [P])."""
         with torch.autocast("cuda", enabled=False):     # demo.forward_model wraps us in fp16 autocast (demo.py:117)
-            return self._forward(x.float().contiguous(), idx, det_thresh, nms_kernel_size, K, is_training)
+            return self._forward(x.float().contiguous(), idx, det_thresh, nms_kernel_size, K, is_training,
+                                 bool(kwargs.get("return_image_index", False)))
 
-    def _forward(self, x, idx, det_thresh, nms_kernel_size, K, is_training):
+    supports_image_index = True
+
+    def _forward(self, x, idx, det_thresh, nms_kernel_size, K, is_training, with_ids=False):
         L = _lib.lib()
         P, ws, stream = self._prepare(x)
         dev, B, G, N, Cdim, Kc = x.device, x.shape[0], P["G"], P["N"], P["C"], P["Kc"]
@@ -405,7 +409,7 @@ class Model(nn.Module):
             counts = ws["counts"].cpu()                       # the one host sync (the reference syncs in torch.where)
             Pn = int(counts.sum())
             if Pn == 0:
-                return []
+                return ([], torch.zeros(0, dtype=torch.int32, device=dev)) if with_ids else []
             base = (torch.cumsum(counts, 0) - counts).to(torch.int32).to(dev)
             det = torch.empty(3, Pn, dtype=torch.int32, device=dev)
             scores_det = torch.empty(Pn, dtype=torch.float32, device=dev)
@@ -480,6 +484,7 @@ class Model(nn.Module):
         if is_training:
             return out
         # 8. per-person dicts (model.py:329-347); v2d / rotmat are computed but not exposed, as in the reference
-        return [{"scores": scores_det[i], "loc": loc[i], "transl": transl[i], "transl_pelvis": out["transl_pelvis"][i],
-                 "rotvec": rotvec[i], "expression": expression[i], "shape": shape[i], "v3d": v3d[i], "j3d": j3d[i], "j2d": j2d[i]}
-                for i in range(Pn)]
+        persons = [{"scores": scores_det[i], "loc": loc[i], "transl": transl[i], "transl_pelvis": out["transl_pelvis"][i],
+                    "rotvec": rotvec[i], "expression": expression[i], "shape": shape[i], "v3d": v3d[i], "j3d": j3d[i], "j2d": j2d[i]}
+                   for i in range(Pn)]
+        return (persons, det[0]) if with_ids else persons
