@@ -295,7 +295,7 @@ def lbs_bench(model, dev, P=160, iters=20):
     K = synthetic.get_camera_K(1288, 8).to(dev)
     det_b = torch.arange(P, device=dev, dtype=torch.int32) // max(1, (P + 7) // 8)
     V = lb["V"]
-    bufs = [f((P + 15) // 16 * 16, lb["Kb"]), f(P, 55, 12), f(P, 24), f(P, V, 3), f(P, V, 2), f(P, 127, 3), f(P, 127, 2), f(P, 3)]
+    bufs = [f((P + 15) // 16 * 16, lb["Kb"]), f((P + 15) // 16 * 16, 768), f(P, 24), f(P, V, 3), f(P, V, 2), f(P, 127, 3), f(P, 127, 2), f(P, 3)]
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def run():

@@ -214,20 +214,23 @@ typedef struct {
     int nb, Kinf;         /* num_betas, max skinning influences per vertex                                   */
     int center_joint;     /* JOINT_NAMES.index(person_center) = 15 ('head'); < 0 = person_center None: nothing is
                              recentred and the pelvis is added to the translation (smpl_layer.py:128-130)       */
-    const void* basis16;  /* f16 [Kb/8][2][3][Vp][8]: 1024 x [posedirs(486) | shapedirs(nb) | exprdirs(10)] as hi + lo      */
+    const void* basis16;  /* f16 [Vp/16][Kb/8][2][3][16][8]: 1024 x [posedirs(486) | shapedirs(nb) | exprdirs(10)] as hi + lo,
+                             tile-major (the slice of a 16-vertex tile is one contiguous block)                   */
     const float* vtemp;   /* [3][Vp]           v_template, fp32                                                */
     const float* J0;      /* [55*3]            J_regressor . v_template                                      */
     const float* JS;      /* [55*3][nb+10]     J_regressor . [shapedirs | exprdirs]                          */
     const int* parents;   /* [55]                                                                            */
-    const int* skin_idx;  /* [V][Kinf]                                                                       */
+    const int* skin_idx;  /* [V][Kinf]         K-sparse skinning list (kept for tools; the kernel reads skin16)        */
     const float* skin_w;  /* [V][Kinf]                                                                       */
+    const void* skin16;   /* f16 [Vp/16][8][2][16][8]: the DENSE skinning weights w[v][j] (joints 55..63 zero), hi + lo,
+                             j = 8 * block + lane-local index: the B operand of the skinning GEMM            */
     const int* extra_vid; /* [21]              vertex ids of joints 55..75                                   */
     const int* lmk_vidx;  /* [51*3]            faces[lmk_faces_idx]                                          */
     const float* lmk_bary;/* [51*3]                                                                          */
 } mhmr_lbs_consts;
 
 /* rotvec [P,53,3], betas [P,nb], expr [P,10], loc [P,2], dist [P], K [B,3,3], det_b [P] (image of each person).
- * Workspaces: ws_F [roundup(P,16), Kb], ws_A [P,55,12], ws_xf [P,24].
+ * Workspaces (fp32-sized, contents are f16 operand matrices): ws_F [roundup(P,16), Kb], ws_A [roundup(P,16), 768], ws_xf [P,24].
  * Outputs: v3d [P,V,3], v2d [P,V,2], j3d [P,127,3], j2d [P,127,2], transl [P,3]  (transl_pelvis = j3d[:,0]). */
 int mhmr_lbs_forward(const mhmr_lbs_consts* c, const float* rotvec, const float* betas, const float* expr,
                      const float* loc, const float* dist, const float* K, const int* det_b, int P, float* ws_F,

@@ -27,19 +27,44 @@ class MhmrError(RuntimeError):
     pass
 
 
+#: per-translation-unit extra flags.  lbs.hip: hipcc's SLP vectoriser packs the per-vertex epilogue into v_pk_*_f32 with op_sel operand
+#: swizzles; that build returned, for about one (person, 16-vertex tile) pair in 10^4, a projection computed with a ZERO focal length
+#: (the y row of K: the other 15 pairs of the same wave were right; deterministic per build, tools/debug_lbs.py).  Scalar f32 code is
+#: also what the guide recommends beside MFMAs (MI355X_MICROARCH.md: packed f32 VALU is an anti-lever there).
+EXTRA_FLAGS = {"lbs.hip": ["-fno-slp-vectorize"]}
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP translation unit for gfx950 into csrc/libmhmr.so (hipcc cross-compiles without a GPU)."""
+    """Compile every HIP translation unit for gfx950 (hipcc cross-compiles without a GPU; one object per source, in parallel) and link
+    csrc/libmhmr.so."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    deps = srcs + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS] + [os.path.abspath(__file__)]
     if not force and os.path.isfile(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+    def compile_one(name):
+        obj = os.path.join(objdir, name.replace(".hip", ".o"))
+        cmd = base + EXTRA_FLAGS.get(name, []) + ["-c", os.path.join(CSRC, name), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise MhmrError(f"hipcc failed on {name}:\n" + res.stdout + res.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise MhmrError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise MhmrError("hipcc link failed:\n" + res.stdout + res.stderr)
     return LIB_PATH
 
 
@@ -70,7 +95,7 @@ class HphDesc(C.Structure):
 
 class LbsConsts(C.Structure):
     _fields_ = ([(n, _i) for n in ("V", "Vp", "Kb", "nb", "Kinf", "center_joint")] +
-                [(n, _vp) for n in ("basis16", "vtemp", "J0", "JS", "parents", "skin_idx", "skin_w", "extra_vid", "lmk_vidx", "lmk_bary")])
+                [(n, _vp) for n in ("basis16", "vtemp", "J0", "JS", "parents", "skin_idx", "skin_w", "skin16", "extra_vid", "lmk_vidx", "lmk_bary")])
 
 
 _SIGS = {

@@ -3,19 +3,25 @@
 //
 //  1. lbs_pose_kernel   (one wave per person)  Rodrigues x55, pose feature, joint regression from the
 //     pre-contracted regressor (J = J0 + JS.[betas, expr]), kinematic chain, root rotation / recentring /
-//     back-projected translation folded into the per-joint skinning transforms, 55 posed joints + projection.
-//  2. lbs_vertex_kernel (the HBM-bound one)   v_posed = v_template + F . D as ONE GEMM, F[p] = [pose_feature(486) | betas | expr]
-//     and D = [posedirs ; shapedirs ; exprdirs], computed to fp32 accuracy on the 16-bit matrix pipe: D (scaled by 2^10 into
-//     the f16 normal range) is stored as an f16 pair hi + lo, F is split hi + lo on the fly, and
-//     F.D = Fh.Dh + Fl.Dh + Fh.Dl (three v_mfma_f32_16x16x32_f16, fp32 accumulate; the dropped Fl.Dl term is 2^-22 relative).
-//     The fp32 MFMA (v_mfma_f32_16x16x4_f32, 1/16 of the 16-bit rate) made this kernel matrix-bound: 108 us for 160 persons,
-//     74 us now.  Ablations of the 74 us: K loop 37 us (64 MB of correctives, ~2 waves per SIMD: latency-bound), skinning
-//     gathers 17 us, stores 5 us, rest 15 us.  Two re-tilings that raise the wave count were built and measured SLOWER (one
-//     16-person group per wave with per-wave basis loads: 82 us, the CU pulls 12x the unique bytes through its L1; the same
-//     with the basis tile shared through LDS and a barrier per K step: 94 us; with a 4-slot LDS-DMA ring three steps ahead: 83 us at
-//     160 persons although 23 instead of 32 us at 20 -- the per-wave skinning set-up then repeats for every 16 persons).  Accumulators leave the MFMA laid out as
-//     (vertex = lane & 15, 4 persons per quad), then the <=K-sparse skinning blend, the folded rigid transform and the pinhole
-//     projection run per lane and v3d / v2d are written out.
+//     back-projected translation folded into the per-joint skinning transforms, 55 posed joints + projection.  It leaves the two
+//     matrix operands of the vertex kernel in MFMA order, each as an f16 pair hi + lo:
+//       F16   F[p] = [pose_feature(486) | betas | expr | 0]
+//       A16   component c of the folded transform [R0 R_w | R0 (t' - pelvis)] of joint j (joints 55..63 zero)
+//     (fragment-major: one 1 KiB block per (person group, part, k step), see the kernel)
+//  2. lbs_vertex_kernel (the HBM-bound one; algorithmic bytes = blend basis 64.5 MB + skin weights 2.7 MB once, 214 KB per person out)
+//     One workgroup = one 16-vertex tile for ALL persons: the tile's slice of the blend basis D = [posedirs ; shapedirs ; exprdirs]
+//     (x 2^10, f16 hi + lo, 98 KB) is DMA'd into LDS once -- HBM sees every basis byte exactly once per launch -- and wave g
+//     works on person group g (16 persons; groups beyond the wave count loop).  Both contractions run on the 16-bit matrix pipe at
+//     fp32 accuracy (x . y = xh.yh + xl.yh + xh.yl, fp32 accumulate; the dropped xl.yl term is 2^-22 relative):
+//       v_posed = v_template + F . D                      16 k-steps x 3 axes x 3 products   (B operand from LDS)
+//       T       = sum_j w[v][j] [R | t]_j  (12 numbers)    2 k-steps x 12 components x 3 products: the skinning blend as a GEMM over
+//                 the DENSE 64 x V weight matrix -- no per-vertex index list, no gathers of joint transforms (they were 17 us of
+//                 the previous kernel's 74 us at 160 persons, 322 MB through the L1)
+//     Both land as (vertex = lane & 15, 4 persons per accumulator quad), so the rigid transform, the camera translation (added in
+//     fp32, exactly where the reference adds it: smpl_layer.py:139-140) and the pinhole projection are per-lane FMAs, and a lane
+//     stores its vertex as one 12-byte and one 8-byte access (16 lanes = 192 / 128 contiguous bytes per person).
+//     History at 160 persons: fp32 MFMA 108 us (matrix-bound), split-f16 blend + sparse gathered skinning 74 us (latency-bound K
+//     loop at ~2 waves per SIMD, basis re-read per 64-person slab), this kernel: see DESIGN.md section 5.
 //  3. lbs_extra_joints_kernel  the 21 vertex-picked joints and 51 barycentric face landmarks.
 #include "mhmr_common.h"
 #include "mhmr_internal.h"
@@ -54,15 +60,33 @@ __device__ __forceinline__ void project(const float* K, const float* x, float* o
 __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, const float* __restrict__ rotvec,
                                                       const float* __restrict__ betas, const float* __restrict__ expr,
                                                       const float* __restrict__ loc, const float* __restrict__ dist,
-                                                      const float* __restrict__ Kmat, const int* __restrict__ det_b, int P,
-                                                      float* __restrict__ F, float* __restrict__ Afold, float* __restrict__ xf,
+                                                      const float* __restrict__ Kmat, const int* __restrict__ det_b, int P, int Pp,
+                                                      _Float16* __restrict__ F16, _Float16* __restrict__ A16, float* __restrict__ xf,
                                                       float* __restrict__ j3d, float* __restrict__ j2d,
                                                       float* __restrict__ transl_out) {
     __shared__ float sR[NJ][9], sJ[NJ][3], sRw[NJ][9], sTw[NJ][3], sX[33];
     const int p = blockIdx.x, j = threadIdx.x;
-    float* Fp = F + (size_t)p * c.Kb;
-    if (p >= P) {  // padding rows of the feature matrix
-        for (int k = j; k < c.Kb; k += 64) Fp[k] = 0.f;
+    // Both operands are stored FRAGMENT-MAJOR: the 64 lanes of a wave read one (person group, part, k step) fragment as 1 KiB of
+    // consecutive bytes (16 B per lane, lane = 16 * (k group) + person-in-group), i.e. eight whole 128-byte lines per wave
+    // instruction; a row-major [person][k] image makes every fragment load touch 16 lines for 64 useful bytes each, and the TA,
+    // not the matrix pipe or HBM, then paces the vertex kernel (93 us at 160 persons).
+    //   F16 [group][hi|lo][Kb/32][64 lanes][8]      A16 [12 comps][hi|lo][group][2][64 lanes][8]
+    const int ngr = Pp / 16, grp = p >> 4, pin = p & 15, nst = c.Kb / 32;
+    auto put_f = [&](int k, float v) {
+        const _Float16 h = (_Float16)v;
+        _Float16* f = F16 + ((((size_t)grp * 2) * nst + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + pin) * 8 + (k & 7);
+        f[0] = h;
+        f[(size_t)nst * 512] = (_Float16)(v - (float)h);
+    };
+    auto put_a = [&](int comp, int joint, float v) {
+        const _Float16 h = (_Float16)v;
+        _Float16* a = A16 + (((((size_t)comp * 2) * ngr + grp) * 2 + (joint >> 5)) * 64 + ((joint >> 3) & 3) * 16 + pin) * 8 + (joint & 7);
+        a[0] = h;
+        a[(size_t)ngr * 1024] = (_Float16)(v - (float)h);
+    };
+    if (p >= P) {  // padding rows of both operand matrices
+        for (int k = j; k < c.Kb; k += 64) put_f(k, 0.f);
+        for (int comp = 0; comp < 12; ++comp) put_a(comp, j, 0.f);
         return;
     }
     const int ncoef = c.nb + 10;
@@ -91,7 +115,7 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
             const float id = (e == 0 || e == 4 || e == 8) ? 1.f : 0.f;
             const float r = id + sn * Km[e] + omc * KK[e];
             sR[j][e] = r;
-            if (j >= 1) Fp[(j - 1) * 9 + e] = r - id;
+            if (j >= 1) put_f((j - 1) * 9 + e, r - id);
         }
         // joints from the pre-contracted regressor
 #pragma unroll
@@ -109,29 +133,43 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
         float v = 0.f;
         if (t < c.nb) v = betas[(size_t)p * c.nb + t];
         else if (t < ncoef) v = expr[(size_t)p * 10 + (t - c.nb)];
-        Fp[k] = v;
+        put_f(k, v);
     }
     __syncthreads();
+    // kinematic chain, one tree LEVEL at a time: every joint whose depth equals the level composes its parent's world transform with its
+    // own (the 55 joints of SMPL-X sit on 10 levels; a single thread walking the 54 edges took 27 us -- more than the vertex kernel at
+    // small person counts)
+    int depth = 0;
+    if (j < NJ)
+        for (int a = c.parents[j]; a >= 0; a = c.parents[a]) ++depth;
     if (j == 0) {
-        // kinematic chain (parents[i] < i), world rotation / translation per joint
 #pragma unroll
         for (int e = 0; e < 9; ++e) sRw[0][e] = sR[0][e];
 #pragma unroll
         for (int a = 0; a < 3; ++a) sTw[0][a] = sJ[0][a];
-        for (int i = 1; i < NJ; ++i) {
-            const int pa = c.parents[i];
+    }
+    int maxdepth = depth;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxdepth = max(maxdepth, __shfl_xor(maxdepth, o));
+    for (int level = 1; level <= maxdepth; ++level) {
+        __syncthreads();
+        if (j < NJ && depth == level) {
+            const int pa = c.parents[j];
             float Rp[9], Rl[9], Rn[9], rel[3], t[3];
 #pragma unroll
-            for (int e = 0; e < 9; ++e) { Rp[e] = sRw[pa][e]; Rl[e] = sR[i][e]; }
+            for (int e = 0; e < 9; ++e) { Rp[e] = sRw[pa][e]; Rl[e] = sR[j][e]; }
             mat3_mul(Rp, Rl, Rn);
 #pragma unroll
-            for (int a = 0; a < 3; ++a) rel[a] = sJ[i][a] - sJ[pa][a];
+            for (int a = 0; a < 3; ++a) rel[a] = sJ[j][a] - sJ[pa][a];
             mat3_vec(Rp, rel, t);
 #pragma unroll
-            for (int e = 0; e < 9; ++e) sRw[i][e] = Rn[e];
+            for (int e = 0; e < 9; ++e) sRw[j][e] = Rn[e];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) sTw[i][a] = t[a] + sTw[pa][a];
+            for (int a = 0; a < 3; ++a) sTw[j][a] = t[a] + sTw[pa][a];
         }
+    }
+    __syncthreads();
+    if (j == 0) {
         // root orientation (roma.rotvec_to_rotmat), translation (inverse_perspective_projection), recentring
         const float* rv = rotvec + (size_t)p * 53 * 3;
         const float th = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
@@ -168,23 +206,26 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
     }
     __syncthreads();
     if (j < 24) xf[(size_t)p * 24 + j] = sX[j];
+    if (j >= NJ) {                                     // joints 55..63: zero columns of the skinning operand
+        for (int comp = 0; comp < 12; ++comp) put_a(comp, j, 0.f);
+    }
     if (j < NJ) {
         float R0[9], Rw[9], Rf[9], tp[3], tt[3], u[3], jj[3];
 #pragma unroll
         for (int e = 0; e < 9; ++e) { R0[e] = sX[e]; Rw[e] = sRw[j][e]; }
         const float pel[3] = {sX[9], sX[10], sX[11]}, o[3] = {sX[12], sX[13], sX[14]};
-        // A'_j = [R_w | t_w - R_w J_j]; folded: [R0 R_w | R0 (t' - pelvis) + o]
+        // A'_j = [R_w | t_w - R_w J_j]; folded: [R0 R_w | R0 (t' - pelvis)]; the camera translation o is added per person in fp32 by
+        // the vertex kernel (skin weights sum to one; the reference adds transl after the LBS, smpl_layer.py:139-140)
         float Jv[3] = {sJ[j][0], sJ[j][1], sJ[j][2]};
         mat3_vec(Rw, Jv, u);
 #pragma unroll
         for (int a = 0; a < 3; ++a) tp[a] = sTw[j][a] - u[a] - pel[a];
         mat3_mul(R0, Rw, Rf);
         mat3_vec(R0, tp, tt);
-        float* ap = Afold + ((size_t)p * NJ + j) * 12;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            ap[r * 4 + 0] = Rf[r * 3]; ap[r * 4 + 1] = Rf[r * 3 + 1]; ap[r * 4 + 2] = Rf[r * 3 + 2];
-            ap[r * 4 + 3] = tt[r] + o[r];
+            put_a(r * 4 + 0, j, Rf[r * 3]); put_a(r * 4 + 1, j, Rf[r * 3 + 1]); put_a(r * 4 + 2, j, Rf[r * 3 + 2]);
+            put_a(r * 4 + 3, j, tt[r]);
         }
         // posed joint in camera space + projection
         float dj[3] = {sTw[j][0] - pel[0], sTw[j][1] - pel[1], sTw[j][2] - pel[2]};
@@ -198,106 +239,146 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
     }
 }
 
-// grid (ceil(Pp / 64) person slabs [fastest], Vp / 64); 4 waves, each a 16-vertex group; up to 4 person groups of 16 per wave.
-__global__ __launch_bounds__(256) void lbs_vertex_kernel(const mhmr_lbs_consts c, const float* __restrict__ F,
-                                                         const float* __restrict__ Afold, const float* __restrict__ xf, int P,
-                                                         int Pp, float* __restrict__ v3d, float* __restrict__ v2d) {
-    typedef Op<MHMR_DT_F16>::V8 H8;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int g = lane >> 4, l15 = lane & 15;
-    const int v0 = blockIdx.y * 64 + w * 16;
-    const int p0 = blockIdx.x * 64;
-    const int npg = min(4, (Pp - p0) / 16);
+// grid = Vp / 16 workgroups (one 16-vertex tile each) of LBS_NW waves; wave w works on person groups w and w + LBS_NW (two per wave
+// at 160 persons).  The k range is consumed in LBS_NQ quarters through TWO LDS buffers of one quarter of the tile's basis slice
+// ([Kb/32][hi|lo][3][16][8] f16 = 24 KiB each): quarter q + 1 is in flight while quarter q is multiplied, and three workgroups share
+// a CU.  (With one buffer and two halves every workgroup of the launch -- all 656 are resident at once -- waited for its DMA at the
+// same time and HBM idled during the MFMAs: 20.7 us at ONE person.)  A operands (F16, A16: L2-resident, identical for every vertex
+// tile) are ordinary loads issued a quarter ahead; they are requested AFTER the quarter's MFMAs and BEFORE the next barrier, so that
+// the one `s_waitcnt vmcnt(0)` per quarter (hipcc waits vmcnt(0) for an ordinary load beside LDS-DMA anyway) only ever waits for
+// things the next quarter needs.
+struct __attribute__((packed, aligned(4))) Vec3 { float x, y, z; };
+struct __attribute__((packed, aligned(4))) Vec2 { float x, y; };
+constexpr int LBS_ROW = 16 * 8 * 2;          // bytes of one (k block, part, axis) row of the tile: 16 vertices x 8 k x f16
+constexpr int LBS_NW = 5, LBS_MAXG = 2;      // waves per workgroup; person groups a wave keeps accumulators for at once
+constexpr int LBS_NQ = 4;                    // k quarters
 
-    f32x4 acc[4][3];
+__global__ __launch_bounds__(64 * LBS_NW, 4) void lbs_vertex_kernel(const mhmr_lbs_consts c, const _Float16* __restrict__ F16,
+                                                                    const _Float16* __restrict__ A16, const float* __restrict__ xf, int P,
+                                                                    int Pp, int g0, float* __restrict__ v3d, float* __restrict__ v2d) {
+    typedef Op<MHMR_DT_F16>::V8 H8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g4 = lane >> 4, l15 = lane & 15;
+    const int v0 = blockIdx.x * 16;
+    const int ns = c.Kb / 32, nsq = ns / LBS_NQ;                    // k-steps of 32, per quarter (4 at Kb = 512)
+    const int rows_q = (c.Kb / 8 / LBS_NQ) * 6;                     // (k block, part, axis) rows of one quarter (96 at Kb = 512)
+    const int ngroups = Pp / 16;
+
+    // one quarter of the tile's basis slice -> LDS buffer `buf`: a wave instruction moves 1 KiB (4 rows of 16 vertices x 16 B), source and
+    // LDS image both lane-linear (tile-major basis: the tile's slice is one contiguous block)
+    const _Float16* bsrc = (const _Float16*)c.basis16 + (size_t)blockIdx.x * (LBS_NQ * rows_q * 128) + lane * 8;
+    auto dma_q = [&](int q, int buf) {
+        for (int i = w; i < rows_q / 4; i += LBS_NW)
+            glds16(bsrc + (size_t)(q * rows_q + 4 * i) * 128, smem + buf * (rows_q * LBS_ROW) + i * (4 * LBS_ROW));
+    };
+    // this wave's A operands of quarter q (fragment-major: 1 KiB per (group, part, k step))
+    H8 ah[LBS_MAXG][4], al[LBS_MAXG][4];
+    auto load_f = [&](int q) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < LBS_MAXG; ++i) {
+            const int g = g0 + w + i * LBS_NW;
+            if (g < ngroups) {
+                const _Float16* fh = F16 + ((((size_t)g * 2) * ns + q * nsq) * 64 + lane) * 8;
+                const _Float16* fl = fh + (size_t)ns * 512;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (s < nsq) { ah[i][s] = *(const H8*)(fh + 512 * s); al[i][s] = *(const H8*)(fl + 512 * s); }
+                }
+            }
+        }
+    };
+    dma_q(0, 0);
+    load_f(0);
+    // dense skin weights of the tile (B operand of the skinning GEMM): lane (v = l15, k group g4) holds joints 8 (4 t + g4) + 0..7
+    H8 wh[2], wl[2];
+    {
+        const _Float16* wp = (const _Float16*)c.skin16 + (size_t)blockIdx.x * (8 * 2 * 128) + l15 * 8;      // tile-major [8][hi|lo][16][8]
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            wh[t] = *(const H8*)(wp + ((4 * t + g4) * 2 + 0) * 128);
+            wl[t] = *(const H8*)(wp + ((4 * t + g4) * 2 + 1) * 128);
+        }
+    }
+    const int v = v0 + l15;
+    const bool vok = v < c.V;
+    const float vt0 = vok ? c.vtemp[v] : 0.f, vt1 = vok ? c.vtemp[c.Vp + v] : 0.f, vt2 = vok ? c.vtemp[2 * c.Vp + v] : 0.f;   // fp32 template
+
+    f32x4 acc[LBS_MAXG][3];
+#pragma unroll
+    for (int i = 0; i < LBS_MAXG; ++i)
 #pragma unroll
         for (int a = 0; a < 3; ++a) acc[i][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // A operand: lane (person p0 + 16 i + l15, k group g) holds F[32 s + 8 g + 0..7]; B operand: lane (vertex v0 + l15, k group g)
-    // holds D[32 s + 8 g + 0..7][axis][vertex] = one 16-byte line of basis16 [Kb/8][hi|lo][3][Vp][8]
-    const float* fp = F + (size_t)(p0 + l15) * c.Kb + 8 * g;
-    const size_t plane = (size_t)c.Vp * 8;                          // halves per (k block, part, axis)
-    const _Float16* bp = (const _Float16*)c.basis16 + (size_t)g * 6 * plane + (size_t)(v0 + l15) * 8;
-    const int ns = c.Kb / 32;
-    for (int s = 0; s < ns; ++s) {
-        const _Float16* bs = bp + (size_t)(4 * s) * 6 * plane;
-        H8 bh[3], bl[3];
+    // ---- v_posed - v_template = F . D ----
+    for (int q = 0; q < LBS_NQ; ++q) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // quarter q's DMA (hipcc does not wait for LDS-DMA by itself) and A operands
+        __syncthreads();                                            // ... of every wave; and everyone is done reading the other buffer
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            bh[a] = *(const H8*)(bs + a * plane);
-            bl[a] = *(const H8*)(bs + (3 + a) * plane);
-        }
+        for (int i = 0; i < LBS_MAXG; ++i)                          // (pins the compiler's own wait for the A operands in front of the DMA)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i < npg) {
-                const float* fr = fp + (size_t)i * 16 * c.Kb + 32 * s;
-                const f32x4 f0 = *(const f32x4*)fr, f1 = *(const f32x4*)(fr + 4);
-                H8 fh, fl;
+            for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(ah[i][s]), "+v"(al[i][s]));
+        if (q + 1 < LBS_NQ) dma_q(q + 1, (q + 1) & 1);
+        const char* brow = smem + (q & 1) * (rows_q * LBS_ROW) + g4 * (6 * LBS_ROW) + l15 * 16;   // + s * 24 rows + (part * 3 + axis) rows
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    fh[e] = (_Float16)f0[e];
-                    fl[e] = (_Float16)(f0[e] - (float)fh[e]);
-                    fh[4 + e] = (_Float16)f1[e];
-                    fl[4 + e] = (_Float16)(f1[e] - (float)fh[4 + e]);
-                }
+        for (int i = 0; i < LBS_MAXG; ++i) {
+            if (g0 + w + i * LBS_NW < ngroups) {
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    acc[i][a] = Op<MHMR_DT_F16>::mfma16(fh, bh[a], acc[i][a]);
-                    acc[i][a] = Op<MHMR_DT_F16>::mfma16(fl, bh[a], acc[i][a]);
-                    acc[i][a] = Op<MHMR_DT_F16>::mfma16(fh, bl[a], acc[i][a]);
+                for (int s = 0; s < 4; ++s) {
+                    if (s < nsq) {
+                        const char* bs = brow + (size_t)s * (24 * LBS_ROW);
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            const H8 bh = *(const H8*)(bs + a * LBS_ROW), bl = *(const H8*)(bs + (3 + a) * LBS_ROW);
+                            acc[i][a] = Op<MHMR_DT_F16>::mfma16(ah[i][s], bh, acc[i][a]);
+                            acc[i][a] = Op<MHMR_DT_F16>::mfma16(al[i][s], bh, acc[i][a]);
+                            acc[i][a] = Op<MHMR_DT_F16>::mfma16(ah[i][s], bl, acc[i][a]);
+                        }
+                    }
                 }
             }
         }
+        if (q + 1 < LBS_NQ) load_f(q + 1);
     }
-
-    const int v = v0 + l15;
-    if (v >= c.V) return;
-    const float vt[3] = {c.vtemp[v], c.vtemp[c.Vp + v], c.vtemp[2 * c.Vp + v]};      // v_template stays fp32
-    // skinning influences of this vertex (first 4 in registers)
-    int si[4];
-    float sw[4];
+    // (no early exit for the padding vertices of the last tile: a lane is a vertex COLUMN of the products but a person ROW of the A
+    // operands, so every lane stays active through the MFMAs; only the stores are guarded)
+    // ---- T = sum_j w[v][j] [R | t]_j (one accumulator per component), rigid transform, camera translation, projection, stores ----
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        si[i] = i < c.Kinf ? c.skin_idx[(size_t)v * c.Kinf + i] : 0;
-        sw[i] = i < c.Kinf ? c.skin_w[(size_t)v * c.Kinf + i] : 0.f;
-    }
+    for (int i = 0; i < LBS_MAXG; ++i) {
+        const int g = g0 + w + i * LBS_NW;
+        if (g >= ngroups) break;
+        const int pg = 16 * g;
+        const _Float16* ap = A16 + ((size_t)g * 2 * 64 + lane) * 8;       // + ((2 cmp + part) * ngroups * 2 + t) * 512
+        const size_t part = (size_t)ngroups * 1024;
+        f32x4 T[12];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (i >= npg) break;
+        for (int cmp = 0; cmp < 12; ++cmp) {
+            T[cmp] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const H8 xh = *(const H8*)(ap + (size_t)(2 * cmp) * part + 512 * t), xl = *(const H8*)(ap + (size_t)(2 * cmp + 1) * part + 512 * t);
+                T[cmp] = Op<MHMR_DT_F16>::mfma16(xh, wh[t], T[cmp]);
+                T[cmp] = Op<MHMR_DT_F16>::mfma16(xl, wh[t], T[cmp]);
+                T[cmp] = Op<MHMR_DT_F16>::mfma16(xh, wl[t], T[cmp]);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int p = p0 + 16 * i + 4 * g + r;
-            if (p >= P) continue;
-            const float vx = acc[i][0][r] * (1.0f / 1024.0f) + vt[0], vy = acc[i][1][r] * (1.0f / 1024.0f) + vt[1],
-                        vz = acc[i][2][r] * (1.0f / 1024.0f) + vt[2];
-            const float* ab = Afold + (size_t)p * NJ * 12;
-            f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0, t2 = t0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float* aj = ab + si[q] * 12;
-                t0 += sw[q] * *(const f32x4*)(aj);
-                t1 += sw[q] * *(const f32x4*)(aj + 4);
-                t2 += sw[q] * *(const f32x4*)(aj + 8);
-            }
-            for (int q = 4; q < c.Kinf; ++q) {
-                const float wq = c.skin_w[(size_t)v * c.Kinf + q];
-                const float* aj = ab + c.skin_idx[(size_t)v * c.Kinf + q] * 12;
-                t0 += wq * *(const f32x4*)(aj);
-                t1 += wq * *(const f32x4*)(aj + 4);
-                t2 += wq * *(const f32x4*)(aj + 8);
-            }
+            const int p = pg + 4 * g4 + r;
+            if (p >= P || !vok) continue;
+            const float vx = acc[i][0][r] * (1.0f / 1024.0f) + vt0, vy = acc[i][1][r] * (1.0f / 1024.0f) + vt1,
+                        vz = acc[i][2][r] * (1.0f / 1024.0f) + vt2;
+            const f32x4* X = (const f32x4*)(xf + (size_t)p * 24 + 12);             // [o (3), K (9)]: three 16-byte loads
+            const f32x4 x0 = X[0], x1 = X[1], x2 = X[2];
             float o3[3];
-            o3[0] = t0[0] * vx + t0[1] * vy + t0[2] * vz + t0[3];
-            o3[1] = t1[0] * vx + t1[1] * vy + t1[2] * vz + t1[3];
-            o3[2] = t2[0] * vx + t2[1] * vy + t2[2] * vz + t2[3];
-            float* vo = v3d + ((size_t)p * c.V + v) * 3;
-            vo[0] = o3[0]; vo[1] = o3[1]; vo[2] = o3[2];
-            float pr[2];
-            project(xf + (size_t)p * 24 + 15, o3, pr);
-            float* po = v2d + ((size_t)p * c.V + v) * 2;
-            po[0] = pr[0]; po[1] = pr[1];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) o3[a] = T[4 * a][r] * vx + T[4 * a + 1][r] * vy + T[4 * a + 2][r] * vz + T[4 * a + 3][r] + x0[a];
+            *(Vec3*)(v3d + ((size_t)p * c.V + v) * 3) = Vec3{o3[0], o3[1], o3[2]};          // one 12-byte store (dword-aligned)
+            // perspective_projection (utils/camera.py:14-27) with one reciprocal instead of three divisions (<= 1 ulp apart)
+            const float iz = __builtin_amdgcn_rcpf(o3[2]);
+            const float yx = o3[0] * iz, yy = o3[1] * iz, yz = o3[2] * iz;
+            *(Vec2*)(v2d + ((size_t)p * c.V + v) * 2) = Vec2{x0[3] * yx + x1[0] * yy + x1[1] * yz, x1[2] * yx + x1[3] * yy + x2[0] * yz};
         }
     }
 }
@@ -349,14 +430,20 @@ extern "C" int mhmr_lbs_forward(const mhmr_lbs_consts* c, const float* rotvec, c
                                 void* stream) {
     if (!c || P < 0) return MHMR_ERR_BAD_ARG;
     if (P == 0) return 0;
-    if (c->Kb % 32 || c->Vp % 64 || c->Kb < 486 + c->nb + 10 || c->Kinf < 1) return MHMR_ERR_BAD_SHAPE;
+    if (c->Kb % 32 || c->Vp % 64 || c->Kb < 486 + c->nb + 10 || !c->skin16) return MHMR_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int Pp = (P + 15) / 16 * 16;
-    hipLaunchKernelGGL(lbs_pose_kernel, dim3(Pp), dim3(64), 0, s, *c, rotvec, betas, expr, loc, dist, Kmat, det_b, P, ws_F, ws_A,
-                       ws_xf, j3d, j2d, transl);
+    if (c->Kb % 128 || c->Kb > 512) return MHMR_ERR_BAD_SHAPE;     // four equal k quarters of at most 4 steps
+    const size_t lds = 2 * (size_t)(c->Kb / 32) * 6 * LBS_ROW;     // two buffers of one quarter of a tile's basis slice: 49152 B at Kb = 512
+    hipLaunchKernelGGL(lbs_pose_kernel, dim3(Pp), dim3(64), 0, s, *c, rotvec, betas, expr, loc, dist, Kmat, det_b, P, Pp,
+                       (_Float16*)ws_F, (_Float16*)ws_A, ws_xf, j3d, j2d, transl);
     MHMR_CHECK_LAUNCH();
+    // one launch covers LBS_NW * LBS_MAXG = 10 person groups (160 persons); more persons take further launches over the same tiles
+    const int ngroups = Pp / 16;
     prof_begin(PROF_LBS, s);
-    hipLaunchKernelGGL(lbs_vertex_kernel, dim3((Pp + 63) / 64, c->Vp / 64), dim3(256), 0, s, *c, ws_F, ws_A, ws_xf, P, Pp, v3d, v2d);
+    for (int g0 = 0; g0 < ngroups; g0 += LBS_NW * LBS_MAXG)
+        hipLaunchKernelGGL(lbs_vertex_kernel, dim3(c->Vp / 16), dim3(64 * LBS_NW), lds, s, *c, (const _Float16*)ws_F, (const _Float16*)ws_A, ws_xf,
+                           P, Pp, g0, v3d, v2d);
     prof_end(PROF_LBS, s, (double)P);
     MHMR_CHECK_LAUNCH();
     hipLaunchKernelGGL(lbs_extra_joints_kernel, dim3(P), dim3(128), 0, s, *c, v3d, v2d, ws_xf, j3d, j2d);

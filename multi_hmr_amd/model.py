@@ -473,7 +473,7 @@ class Model(nn.Module):
         V = lb["V"]
         v3d, v2d = f(Pn, V, 3), f(Pn, V, 2)
         j3d, j2d, transl = f(Pn, 127, 3), f(Pn, 127, 2), f(Pn, 3)
-        ws_F, ws_A, ws_xf = f(roundup(Pn, 16), lb["Kb"]), f(Pn, 55, 12), f(Pn, 24)
+        ws_F, ws_A, ws_xf = f(roundup(Pn, 16), lb["Kb"]), f(roundup(Pn, 16), 768), f(Pn, 24)
         _lib.check(L.mhmr_lbs_forward(C.byref(P["lbs_struct"]), rotvec.data_ptr(), shape.data_ptr(), expression.data_ptr(), loc.data_ptr(),
                                       dist.data_ptr(), K.data_ptr(), det[0].data_ptr(), Pn, ws_F.data_ptr(), ws_A.data_ptr(),
                                       ws_xf.data_ptr(), v3d.data_ptr(), v2d.data_ptr(), j3d.data_ptr(), j2d.data_ptr(), transl.data_ptr(),

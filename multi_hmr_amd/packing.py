@@ -57,10 +57,11 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
     """SMPL-X arrays (keys of SMPLX_NEUTRAL.npz) -> mhmr_lbs_consts tensors.
 
     * blend basis rows = [posedirs (486) | shapedirs[:, :, :nb] | shapedirs[:, :, 300:310] | 0-pad], scaled by 2^10 into the f16
-      normal range and stored as an f16 pair hi + lo, [Kb/8][hi|lo][3][Vp][8]: one 16-byte line per lane is the 16x16x32 MFMA
-      operand for 8 consecutive k; the template stays fp32 ([3][Vp]);
+      normal range and stored as an f16 pair hi + lo, tile-major [Vp/16][Kb/8][hi|lo][3][16][8]: one 16-byte line per lane is the
+      16x16x32 MFMA operand for 8 consecutive k; the template stays fp32 ([3][Vp]);
     * the dense joint regressor is pre-contracted with the template and the blend shapes (J = J0 + JS.coef);
-    * skinning weights become a K-sparse (index, weight) list, K = max non-zeros per vertex.
+    * skinning weights: the dense [64, Vp] matrix as an f16 pair hi + lo in MFMA operand order (``skin16``; the kernel blends the
+      joint transforms as a GEMM), plus the K-sparse (index, weight) list, K = max non-zeros per vertex (tools / tests).
     """
     from .synthetic import SMPLX_EXTRA_JOINT_VERTS
     f64 = lambda a: np.asarray(a, dtype=np.float64)
@@ -79,8 +80,10 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
     Ds = (D * 1024.0).astype(np.float32)
     hi = Ds.astype(np.float16)
     lo = (Ds - hi.astype(np.float32)).astype(np.float16)
-    lay = lambda a: a.reshape(Kb // 8, 8, 3, Vp).transpose(0, 2, 3, 1)                      # [Kb/8, 3, Vp, 8]
-    basis16 = np.ascontiguousarray(np.stack([lay(hi), lay(lo)], axis=1))                    # [Kb/8, 2, 3, Vp, 8]
+    # tile-major: the slice of one 16-vertex tile is ONE contiguous 96 KiB block [Kb/8][hi|lo][3][16][8] (the kernel DMAs it into
+    # LDS in two halves: whole DRAM pages instead of 256-byte pieces 168 KB apart)
+    lay = lambda a: a.reshape(Kb // 8, 8, 3, Vp // 16, 16).transpose(3, 0, 2, 4, 1)         # [Vp/16, Kb/8, 3, 16, 8]
+    basis16 = np.ascontiguousarray(np.stack([lay(hi), lay(lo)], axis=2))                    # [Vp/16, Kb/8, 2, 3, 16, 8]
     vtemp = np.zeros((3, Vp), dtype=np.float32)
     vtemp[:, :V] = v_t.T
 
@@ -95,6 +98,14 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
     skin_idx = order.astype(np.int32)
     skin_w = np.take_along_axis(W, order, axis=1).astype(np.float32)
 
+    # dense weights as the B operand of the skinning GEMM: [8 joint blocks][hi | lo][Vp][8], joints 55..63 and vertices >= V zero
+    Wd = np.zeros((64, Vp), dtype=np.float32)
+    Wd[: W.shape[1], :V] = W.T.astype(np.float32)
+    whi = Wd.astype(np.float16)
+    wlo = (Wd - whi.astype(np.float32)).astype(np.float16)
+    wlay = lambda a: a.reshape(8, 8, Vp // 16, 16).transpose(2, 0, 3, 1)                      # [Vp/16, 8, 16, 8]
+    skin16 = np.ascontiguousarray(np.stack([wlay(whi), wlay(wlo)], axis=2))                   # [Vp/16, 8, 2, 16, 8]
+
     parents = np.asarray(data["kintree_table"])[0].astype(np.int64).copy()
     parents[0] = -1
     faces = np.asarray(data["f"], dtype=np.int64)
@@ -104,6 +115,7 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
         "V": V, "Vp": Vp, "Kb": Kb, "nb": num_betas, "Kinf": Kinf, "center_joint": person_center_idx,
         "basis16": t(basis16, torch.float16), "vtemp": t(vtemp, torch.float32), "J0": t(J0, torch.float32), "JS": t(JS.reshape(55 * 3, ncoef), torch.float32),
         "parents": t(parents.astype(np.int32), torch.int32), "skin_idx": t(skin_idx, torch.int32), "skin_w": t(skin_w, torch.float32),
+        "skin16": t(skin16, torch.float16),
         "extra_vid": t(np.asarray(SMPLX_EXTRA_JOINT_VERTS, dtype=np.int32), torch.int32), "lmk_vidx": t(lmk_vidx, torch.int32),
         "lmk_bary": t(np.asarray(data["lmk_bary_coords"], dtype=np.float32), torch.float32),
         "faces": faces,
@@ -114,6 +126,6 @@ def lbs_consts_struct(p: dict) -> "_lib.LbsConsts":
     c = _lib.LbsConsts()
     for k in ("V", "Vp", "Kb", "nb", "Kinf", "center_joint"):
         setattr(c, k, int(p[k]))
-    for k in ("basis16", "vtemp", "J0", "JS", "parents", "skin_idx", "skin_w", "extra_vid", "lmk_vidx", "lmk_bary"):
+    for k in ("basis16", "vtemp", "J0", "JS", "parents", "skin_idx", "skin_w", "skin16", "extra_vid", "lmk_vidx", "lmk_bary"):
         setattr(c, k, p[k].data_ptr())
     return c

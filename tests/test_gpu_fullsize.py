@@ -56,7 +56,7 @@ def test_lbs_160_persons_linear_in_betas_at_zero_pose(smplx_data):
     def run(betas):
         f = lambda *s: torch.zeros(*s, device=dev)
         v3d, v2d, j3d, j2d, tr = f(P, V, 3), f(P, V, 2), f(P, 127, 3), f(P, 127, 2), f(P, 3)
-        ws = [f(packing.roundup(P, 16), pk["Kb"]), f(P, 55, 12), f(P, 24)]
+        ws = [f(packing.roundup(P, 16), pk["Kb"]), f(packing.roundup(P, 16), 768), f(P, 24)]
         _lib.check(L.mhmr_lbs_forward(C.byref(cs), pose.data_ptr(), betas.data_ptr(), expr.data_ptr(), loc.data_ptr(), dist.data_ptr(),
                                       K.data_ptr(), det_b.data_ptr(), P, *[w.data_ptr() for w in ws], v3d.data_ptr(), v2d.data_ptr(),
                                       j3d.data_ptr(), j2d.data_ptr(), tr.data_ptr(), st), "lbs")

@@ -338,7 +338,7 @@ def test_lbs_against_oracle(L, smplx_data, P, center):
     V = pk["V"]
     f = lambda *s: torch.zeros(*s, device=dev())
     v3d, v2d, j3d, j2d, transl = f(P, V, 3), f(P, V, 2), f(P, 127, 3), f(P, 127, 2), f(P, 3)
-    wsF, wsA, wsX = f(packing.roundup(P, 16), pk["Kb"]), f(P, 55, 12), f(P, 24)
+    wsF, wsA, wsX = f(packing.roundup(P, 16), pk["Kb"]), f(packing.roundup(P, 16), 768), f(P, 24)
     args = [d(pose), d(shape), d(expr), d(loc), d(dist), d(K), d(det_b, torch.int32)]
     _lib.check(L.mhmr_lbs_forward(C.byref(cs), *[a.data_ptr() for a in args], P, wsF.data_ptr(), wsA.data_ptr(), wsX.data_ptr(),
                                   v3d.data_ptr(), v2d.data_ptr(), j3d.data_ptr(), j2d.data_ptr(), transl.data_ptr(), stream()), "lbs")

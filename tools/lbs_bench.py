@@ -16,7 +16,7 @@ shape, expr = torch.randn(P, 10, generator=g, device=dev), torch.randn(P, 10, ge
 loc, dist = 1288 * torch.rand(P, 2, generator=g, device=dev), 2 + 6 * torch.rand(P, 1, generator=g, device=dev)
 K = synthetic.get_camera_K(1288, 8).to(dev); det_b = (torch.arange(P, device=dev, dtype=torch.int32) * 8 // P).contiguous()
 V = lb["V"]
-bufs = [f((P + 15) // 16 * 16, lb["Kb"]), f(P, 55, 12), f(P, 24), f(P, V, 3), f(P, V, 2), f(P, 127, 3), f(P, 127, 2), f(P, 3)]
+bufs = [f((P + 15) // 16 * 16, lb["Kb"]), f((P + 15) // 16 * 16, 768), f(P, 24), f(P, V, 3), f(P, V, 2), f(P, 127, 3), f(P, 127, 2), f(P, 3)]
 st = torch.cuda.current_stream(dev).cuda_stream
 run = lambda: _lib.check(L.mhmr_lbs_forward(C.byref(cs), pose.data_ptr(), shape.data_ptr(), expr.data_ptr(), loc.data_ptr(), dist.data_ptr(),
                                             K.data_ptr(), det_b.data_ptr(), P, *[b.data_ptr() for b in bufs], st), "lbs")
