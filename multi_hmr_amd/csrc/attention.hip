@@ -36,6 +36,10 @@
 // flight); one barrier per KV tile.  The landing wait is an EXPLICIT `s_waitcnt vmcnt(0)`: inside a loop hipcc
 // (ROCm 7.2) does NOT emit the vmcnt wait for LDS-DMA in front of __syncthreads() -- it hoisted it out of the loop -- and
 // the kernel then read tiles that had not landed (run-to-run different results; tools/determinism.py).
+//
+// Measured and rejected on the MODE 3 form (B = 32, H = 16, T = 4097, same process, interleaved): K fragments double-buffered one
+// k-step ahead with pinned issue order (120 VGPRs) 933-936 vs 900-953 TFLOP/s f16 for this form, 990-997 vs 945-1016 bf16; 8 waves
+// with a 3-slot ring 862-908; both together 954 / 1006: all inside the run-to-run spread of the plain 4-wave form, which stays.
 #include <stdlib.h>
 #include "mhmr_common.h"
 #include "mhmr_internal.h"

@@ -217,7 +217,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
             // tile).  The residual of pass s + 1 is requested before pass s is staged (registers: the operand fragments, dead
             // between K loops): proj 0.414 -> 0.365 ms, fc2 1.01 -> 0.975 ms.  Deeper prefetch (2 passes, or growing as staged
             // passes free their accumulators) measured no better: with every CU in its epilogue at once the 134 MB round is at
-            // the HBM floor.
+            // the HBM floor.  Also measured and rejected (round 2): the residual tile as the accumulators' INITIAL value (LayerScale
+            // folded into W, epilogue write-only) -- the 32 fragment-shaped loads per lane (16 rows x 64 B each) cost more than the
+            // read-modify-write they replace: proj 0.351 -> 0.372 ms, fc2 0.977 -> 1.006 ms (f16).
             constexpr int RD = 1;
             const int c = lane & 15;
             // 32-bit byte offsets from the uniform base (eligibility guarantees M * ldo * 4 < 2^32): one VGPR per address

@@ -48,7 +48,7 @@ def main():
     M = B * Tp
     rnd = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(tdt)
     if a.only in ("", "gemm"):
-        shapes = [("qk   (EPI_OP16)", 2 * C, C, _lib.EPI_OP16), ("v    (EPI_VT)", C, C, _lib.EPI_VT), ("proj (EPI_RESID)", C, C, _lib.EPI_RESID),
+        shapes = [("qk   (EPI_OP16)", 2 * C, C, _lib.EPI_OP16), ("qk   (EPI_OP16_QK)", 2 * C, C, _lib.EPI_OP16_QK), ("v    (EPI_VT)", C, C, _lib.EPI_VT), ("proj (EPI_RESID)", C, C, _lib.EPI_RESID),
                   ("fc1  (EPI_GELU)", 4 * C, C, _lib.EPI_OP16_GELU), ("fc2  (EPI_RESID)", C, 4 * C, _lib.EPI_RESID)]
         for name, N, K, epi in shapes:
             A, W = rnd(M, K), (torch.randn(N, K, device=dev) / math.sqrt(K)).to(tdt)
