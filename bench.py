@@ -35,7 +35,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from multi_hmr_amd import Model, _lib, collate, synthetic  # noqa: E402
+from multi_hmr_amd import Model, _lib, collate  # noqa: E402
+import synthetic  # noqa: E402
 
 PEAK_MFMA_TFLOPS = 2500.0     # bf16/f16 dense, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0         # HBM3E spec, same table (6.29 TB/s measured float4 copy)

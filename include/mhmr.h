@@ -32,7 +32,7 @@ extern "C" {
 
 /* GEMM epilogues of mhmr_gemm16 */
 #define MHMR_EPI_OP16 0      /* out16 = acc + bias                                           */
-#define MHMR_EPI_OP16_GELU 1 /* out16 = gelu_erf(acc + bias)            (DINOv2 Mlp fc1)     */
+#define MHMR_EPI_OP16_GELU 1 /* out16 = gelu(acc + bias), erf form, 3-term A&S 7.1.25 erfc: |abs err| < 2.6e-5 (Mlp fc1) */
 #define MHMR_EPI_OP16_RELU 2 /* out16 = relu(acc + bias)                (regression_mlp, model.py:596-609) */
 #define MHMR_EPI_RESID 3     /* out32 += gamma * (acc + bias)           (LayerScale + residual) */
 #define MHMR_EPI_PATCH 4     /* patch-embed: + bias + pos-embed, scattered to token rows     */

@@ -24,11 +24,11 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import _lib, packing, synthetic, vit
+from . import _lib, constants, packing, vit
 from .anny_hph import HPH
 from .model import PATCH, _Encoder, _Holder
 from .packing import roundup
-from .synthetic import VIT_CFG
+from .constants import VIT_CFG
 
 PHENOTYPE_KEYS = ["age", "gender", "weight", "height", "muscle", "proportions"]     # multi_hmr.py:162
 
@@ -67,12 +67,12 @@ class Multi_HMR(nn.Module):
         assert self.img_size % self.encoder.patch_size == 0, "Invalid img size"
         self.patch_size = self.encoder.patch_size
         G = img_size // self.patch_size
-        self.register_buffer("dec_pos_emb", torch.from_numpy(synthetic.anny_sincos_pos_embed(xat_dim, G)).float())
+        self.register_buffer("dec_pos_emb", torch.from_numpy(constants.anny_sincos_pos_embed(xat_dim, G)).float())
         self.dec_to_token = nn.Linear(self.encoder.embed_dim, xat_dim)
         self.decoder = HPH(dim=xat_dim, depth=xat_depth, heads=xat_heads, dim_head=xat_dim_head, mlp_dim=xat_mlp_dim, dropout=xat_dropout,
                            precision=self.precision)
         D = xat_dim
-        self.n_joints, self.num_betas = synthetic.ANNY_NUM_JOINTS, num_betas
+        self.n_joints, self.num_betas = constants.ANNY_NUM_JOINTS, num_betas
         J = self.n_joints
         self.mlp_offset = nn.Sequential(nn.Linear(D, D), nn.ReLU(), nn.Linear(D, 2))
         self.mlp_pose = nn.Sequential(nn.Linear(D + J * 6, D), nn.ReLU(), nn.Linear(D, J * 6))
@@ -84,8 +84,8 @@ class Multi_HMR(nn.Module):
         if self.body_model is not None:
             self.person_center_idx = list(self.body_model.bone_labels).index(person_center)
         self.eye = nn.Parameter(torch.eye(3).unsqueeze(0), requires_grad=False)
-        self.useful_rotmat = nn.Parameter(torch.tensor(synthetic.ANNY_USEFUL_ROTMAT).unsqueeze(0), requires_grad=False)
-        self.register_buffer("init_body_pose", synthetic.anny_init_body_pose())
+        self.useful_rotmat = nn.Parameter(torch.tensor(constants.ANNY_USEFUL_ROTMAT).unsqueeze(0), requires_grad=False)
+        self.register_buffer("init_body_pose", constants.anny_init_body_pose())
         self._packed, self._ws = None, vit.WorkspaceCache()
         for p in self.parameters():
             p.requires_grad_(False)

@@ -18,7 +18,7 @@ from torch import nn
 
 from . import _lib, packing, vit
 from .packing import roundup
-from .synthetic import SMPLX_JOINT_NAMES, VIT_CFG
+from .constants import SMPLX_JOINT_NAMES, VIT_CFG
 
 PATCH = 14
 SMPLX_DIR = "models"                           # reference utils/constants.py:7

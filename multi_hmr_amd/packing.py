@@ -63,7 +63,7 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
     * skinning weights: the dense [64, Vp] matrix as an f16 pair hi + lo in MFMA operand order (``skin16``; the kernel blends the
       joint transforms as a GEMM), plus the K-sparse (index, weight) list, K = max non-zeros per vertex (tools / tests).
     """
-    from .synthetic import SMPLX_EXTRA_JOINT_VERTS
+    from .constants import SMPLX_EXTRA_JOINT_VERTS
     f64 = lambda a: np.asarray(a, dtype=np.float64)
     v_t = f64(data["v_template"])
     V = v_t.shape[0]

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from multi_hmr_amd.synthetic import SMPLX_EXTRA_JOINT_VERTS, SMPLX_JOINT_NAMES
+from multi_hmr_amd.constants import SMPLX_EXTRA_JOINT_VERTS, SMPLX_JOINT_NAMES
 
 JOINT_NAMES = list(SMPLX_JOINT_NAMES) + [f"contour_{i}" for i in range(17)]  # smplx.joint_names.JOINT_NAMES
 

@@ -15,11 +15,11 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def smplx_data():
-    from multi_hmr_amd import synthetic
+    import synthetic
     return synthetic.make_smplx_data(seed=0)
 
 
 @pytest.fixture(scope="session")
 def mean_params():
-    from multi_hmr_amd import synthetic
+    import synthetic
     return synthetic.make_mean_params(seed=0)

@@ -1,7 +1,7 @@
 """Generate tests/golden/*.npz by running the REFERENCE's own model code verbatim (oracle/ref_shim.py).
 
 Run in the build container only (needs /root/reference):  python tests/golden/make_golden.py
-Inputs are re-derivable from seeds (multi_hmr_amd.synthetic); outputs of the reference's
+Inputs are re-derivable from seeds (synthetic.py at the repository root); outputs of the reference's
 ``Model.forward`` are stored.  The third-party pieces (DINOv2 / smplx / roma) are the restatements in
 oracle/ -- the reference does not vendor them -- so these vectors pin every *reference-authored* line on
 the path (detection, camera embedding, HPH glue + decoder, SMPL layer post-processing, collation).
@@ -17,7 +17,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-from multi_hmr_amd import synthetic  # noqa: E402
+import synthetic  # noqa: E402
 from oracle import ref_shim  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -16,7 +16,7 @@ from torch import nn
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-from multi_hmr_amd import synthetic  # noqa: E402
+import synthetic  # noqa: E402
 from oracle import ref_shim  # noqa: E402
 
 CASE = dict(backbone="dinov2_vits14", img_size=224, depth_override=3, xat_depth=3, batch=3, persons=[2, 0, 3], seed=7)

@@ -22,7 +22,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-from multi_hmr_amd import synthetic  # noqa: E402
+import synthetic  # noqa: E402
 from oracle import ref_shim  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))

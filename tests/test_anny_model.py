@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from multi_hmr_amd import synthetic
+import synthetic
 from multi_hmr_amd.anny_model import Multi_HMR
 
 HERE = os.path.dirname(__file__)

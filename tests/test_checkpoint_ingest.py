@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 import torch
 
-from multi_hmr_amd import Model, load_model, synthetic
+from multi_hmr_amd import Model, load_model
+import synthetic
 
 
 @pytest.fixture()

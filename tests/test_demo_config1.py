@@ -15,7 +15,7 @@ import torch
 
 import parity
 from multi_hmr_amd import preprocess as pp
-from multi_hmr_amd import synthetic
+import synthetic
 from oracle import preprocess_ref as ref
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "demo_672_s.npz"))

@@ -8,7 +8,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from multi_hmr_amd import Model, _lib, packing, synthetic  # noqa: E402
+from multi_hmr_amd import Model, _lib, packing  # noqa: E402
+import synthetic  # noqa: E402
 
 
 @pytest.fixture(scope="module")

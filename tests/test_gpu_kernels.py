@@ -9,7 +9,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from multi_hmr_amd import _lib, packing, synthetic  # noqa: E402
+from multi_hmr_amd import _lib, packing  # noqa: E402
+import synthetic  # noqa: E402
 
 DTYPES = [("f16", _lib.DT_F16, torch.float16, 2e-3), ("bf16", _lib.DT_BF16, torch.bfloat16, 1.6e-2)]
 
@@ -36,6 +37,29 @@ def rel(a, b):
 def maxrel(a, b):
     a, b = a.double(), b.double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def test_gelu_epilogue_max_abs_error(L):
+    """The fc1 epilogue's GELU is the three-term Abramowitz-Stegun 7.1.25 erfc form (csrc/mhmr_common.h gelu_fast), not erff:
+    swept over x = a_m + b_n in [-10, 10] (step ~ 4e-5) through the GEMM itself (A[:, 0] = a, W[:, 0] = 1, bias = b), the stored
+    f16 value stays within 2.6e-5 absolute + half an f16 ulp of the exact x Phi(x)."""
+    M, N, K = 4096, 128, 64
+    a = torch.linspace(-10, 10, M).half()
+    b = torch.linspace(0, 20.0 / M, N)
+    A = torch.zeros(M, K, dtype=torch.float16)
+    A[:, 0] = a
+    W = torch.zeros(N, K, dtype=torch.float16)
+    W[:, 0] = 1
+    out = torch.zeros(M, N, dtype=torch.float16, device=dev())
+    Ad, Wd, bd = A.to(dev()), W.to(dev()), b.to(dev())
+    _lib.check(L.mhmr_gemm16(Ad.data_ptr(), K, Wd.data_ptr(), K, M, N, K, bd.data_ptr(), None, out.data_ptr(), N, None, 0, 128, 1, M,
+                             _lib.EPI_OP16_GELU, _lib.DT_F16, stream()), "gemm")
+    x = (a.float()[:, None] + b[None, :]).double()
+    ref = 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+    err = (out.cpu().double() - ref).abs()
+    bound = 2.6e-5 + 2.0 ** -11 * ref.abs() + 2.0 ** -25         # (+ the f16 subnormal step)
+    assert bool((err <= bound).all()), float((err - bound).max())
+    assert float(err.max()) > 1e-6                                # the sweep really exercised the approximation
 
 
 def swap23(t):

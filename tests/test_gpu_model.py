@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 
 import make_golden  # noqa: E402
 import parity  # noqa: E402
-from multi_hmr_amd import Model, synthetic  # noqa: E402
+from multi_hmr_amd import Model  # noqa: E402
+import synthetic  # noqa: E402
 from oracle import roma_ref  # noqa: E402
 from parity import CHECKED, TOL, rel  # noqa: E402
 

@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 import torch
 
-from multi_hmr_amd import Model, _lib, packing, synthetic
+from multi_hmr_amd import Model, _lib, packing
+import synthetic
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -91,3 +92,18 @@ def test_no_cpu_fallback(smplx_data, mean_params):
     for f in os.listdir(os.path.join(ROOT, "multi_hmr_amd")):
         if f.endswith(".py"):
             assert "oracle" not in open(os.path.join(ROOT, "multi_hmr_amd", f)).read().replace("the oracle", "").replace("CPU oracle", ""), f
+
+
+def test_gelu_three_term_erfc_error_bound():
+    """The constants of csrc/mhmr_common.h gelu_fast (Abramowitz-Stegun 7.1.25, three terms) restated in float64: the form itself
+    is within 2.6e-5 absolute of x Phi(x) everywhere (the GPU sweep of the epilogue is tests/test_gpu_kernels.py)."""
+    import math
+    from scipy.special import erf
+    x = np.linspace(-12, 12, 400001)
+    ax = np.abs(x)
+    t = 1 / (1 + ax * 0.47047 * 0.70710678118654752440)
+    p = t * (0.3480242 + t * (-0.0958798 + t * 0.7478556))
+    u = ax * 0.84932180028801904272
+    g = np.maximum(x, 0) - 0.5 * ax * p * np.exp2(-(u * u))
+    ref = 0.5 * x * (1 + erf(x / math.sqrt(2)))
+    assert np.abs(g - ref).max() < 2.6e-5

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import dinov2_ref, roma_ref, smplx_ref
-from multi_hmr_amd import synthetic
+import synthetic
 
 
 # ------------------------------------------------------------------ DINOv2

@@ -1,7 +1,8 @@
 import ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from multi_hmr_amd import _lib, packing, synthetic
+from multi_hmr_amd import _lib, packing
+import synthetic
 from oracle import smplx_ref
 from oracle.multihmr_ref import smpl_layer_forward
 P = int(sys.argv[1])

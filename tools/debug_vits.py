@@ -4,7 +4,8 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
-from multi_hmr_amd import Model, synthetic
+from multi_hmr_amd import Model
+import synthetic
 from oracle import dinov2_ref
 
 name, S = sys.argv[1], int(sys.argv[2])

@@ -3,7 +3,8 @@
 import ctypes as C, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from multi_hmr_amd import _lib, packing, synthetic
+from multi_hmr_amd import _lib, packing
+import synthetic
 if os.environ.get("MHMR_LIB"):
     _lib.LIB_PATH = os.environ["MHMR_LIB"]
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 160

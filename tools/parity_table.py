@@ -5,7 +5,8 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import make_golden
-from multi_hmr_amd import Model, synthetic
+from multi_hmr_amd import Model
+import synthetic
 sm, mp = synthetic.make_smplx_data(seed=0), synthetic.make_mean_params(seed=0)
 for name in ("vitl_224_train", "vitb_224_train", "vits_224_train"):
     cfg = make_golden.CASES[name]

@@ -20,7 +20,7 @@ import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from multi_hmr_amd import synthetic  # noqa: E402
+import synthetic  # noqa: E402
 from oracle.multihmr_ref import OracleModel  # noqa: E402
 from oracle import dinov2_ref  # noqa: E402
 

@@ -1,6 +1,7 @@
 import torch, sys
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from multi_hmr_amd import Model, synthetic
+from multi_hmr_amd import Model
+import synthetic
 sm, mp = synthetic.make_smplx_data(0), synthetic.make_mean_params(0)
 m = Model(backbone="dinov2_vitl14", img_size=896, smplx_data=sm, mean_params=mp, precision="bf16")
 m.load_state_dict(synthetic.make_state_dict("dinov2_vitl14", 896, seed=0, mean_params=mp), strict=True)

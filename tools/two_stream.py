@@ -4,7 +4,8 @@ kernels of independent halves)."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from multi_hmr_amd import Model, synthetic
+from multi_hmr_amd import Model
+import synthetic
 
 dev = torch.device("cuda:0")
 sm, mp = synthetic.make_smplx_data(seed=0), synthetic.make_mean_params()
