@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--persons", type=int, default=8, help="pinned detections per image")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (cpu_baseline AND parity)")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline side measurements, the other configs and the other precision")
+    ap.add_argument("--only-headline-kernels", action="store_true",
+                    help="profiling runs (rocprofv3 --pmc): the headline forward and its roofline passes only, so that per-kernel "
+                         "averages are not mixed with the other configurations' shapes")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -234,13 +237,12 @@ def main():
             model(x, idx=idx, K=K, is_training=True)
         n_a, ms_a, _ = prof_collect()
         att_tf = attn_fl * B * reps / (ms_a * 1e-3) / 1e12 if ms_a > 0 else 0.0
-        att_key = next((k for k in (pmc or {}) if k.startswith("attn_kernel")), None)
         result["roofline_attention"] = {
             "kernel": "attn_kernel (flash, d=64; reference level in the accumulator init)", "bound": "mfma", "achieved": round(att_tf, 1),
             "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(att_tf / PEAK_MFMA_TFLOPS, 4),
-            "traffic": pmc[att_key].get("total_bytes_per_launch") if att_key else None, "launches": n_a,
+            "traffic": pmc.get("_attention_bytes_per_call") if pmc else None, "launches": n_a,
             "avg_launch_ms": round(ms_a / max(n_a, 1), 4), "share_of_step": round(ms_a / reps / ms_step, 3)}
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and not args.no_extras and not args.only_headline_kernels:
         result["lbs"] = lbs_bench(model, dev, P=160)
         result["ms_per_person_lbs"] = result["lbs"]["ms_per_person"]
         result["lbs_small_batches"] = {f"P={p}": lbs_bench(model, dev, P=p)["ms_per_person"] for p in (20, 1)}
@@ -249,7 +251,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"], result["parity"] = cpu_baseline_and_parity(args, smplx_data, mean_params, model, x, K, idx, out_last)
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and not args.only_headline_kernels:
         # release the headline model's workspace before the other configurations
         del model, out_last
         torch.cuda.empty_cache()

@@ -6,31 +6,51 @@ If <dir>/SQ_counter_collection.csv exists (a third pass: SQ_VALU_MFMA_BUSY_CYCLE
 SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE) it adds per kernel: matrix-pipe busy fraction =
 SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), the effective shader clock = (GRBM_GUI_ACTIVE / 8) / duration,
 and the LDS bank-conflict share of LDS-active cycles.
-usage: tools/pmc_traffic.py <dir with FETCH_SIZE_counter_collection.csv, WRITE_SIZE_counter_collection.csv> > profiles/x.json"""
-import os
-import collections, csv, json, re, sys
+<dir>/lbs/ (optional) holds the same passes over tools/lbs_bench.py 160: the SMPL-X layer's kernels at P = 160 are taken from
+there (inside the forward the layer runs at other person counts).  The summary records the sha256 prefix of the libmhmr.so it
+was measured on (`_lib_sha16`); bench.py reports `traffic` from it only when that matches the library it is running.
+usage: tools/pmc_traffic.py <dir with FETCH_SIZE_counter_collection.csv, WRITE_SIZE_counter_collection.csv> > profiles/rNN_pmc.json"""
+import collections, csv, glob, hashlib, json, os, re, sys
 d = sys.argv[1]
-out = collections.OrderedDict()
-for c, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
-    for r in csv.DictReader(open(f"{d}/{c}_counter_collection.csv")):
-        m = re.search(r"(gemm256_kernel<\d, \d>|gemm_kernel<\d, \d>|attn_kernel<[^>]*>|layernorm_kernel<[^>]*>|lbs_vertex_kernel)", r["Kernel_Name"])
-        if m:
-            e = out.setdefault(m.group(1), {"FETCH_SIZE": [], "WRITE_SIZE": []})
-            e[c].append(float(r["Counter_Value"]) * 1024 * mult)
-res = {}
-for k, e in out.items():
-    rd, wr = sum(e["FETCH_SIZE"]) / max(len(e["FETCH_SIZE"]), 1), sum(e["WRITE_SIZE"]) / max(len(e["WRITE_SIZE"]), 1)
-    res[k] = {"launches": len(e["FETCH_SIZE"]), "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr), "total_bytes_per_launch": round(rd + wr)}
-sq_path = f"{d}/SQ_counter_collection.csv"
-if os.path.isfile(sq_path):
-    sq = collections.OrderedDict()
-    for r in csv.DictReader(open(sq_path)):
-        m = re.search(r"(gemm256_kernel<\d, \d>|gemm_kernel<\d, \d>|attn_kernel<[^>]*>|layernorm_kernel<[^>]*>|lbs_vertex_kernel)", r["Kernel_Name"])
-        if m:
-            e = sq.setdefault(m.group(1), collections.defaultdict(list))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PAT = re.compile(r"(gemm256_kernel<\d, \d>|gemm_kernel<\d, \d>|attn_kernel<[^>]*>|layernorm_kernel<[^>]*>|lbs_vertex_kernel|lbs_pose_kernel|lbs_extra_joints_kernel)")
+
+
+def find(dirname, counter):
+    hits = [p for p in glob.glob(f"{dirname}/**/{counter}_counter_collection.csv", recursive=True) if "/lbs/" not in p[len(dirname):] or dirname.rstrip("/").endswith("lbs")]
+    return hits[0] if hits else None
+
+
+def traffic(dirname, keep):
+    out = collections.OrderedDict()
+    for c, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        path = find(dirname, c)
+        if not path:
+            continue
+        for r in csv.DictReader(open(path)):
+            m = PAT.search(r["Kernel_Name"])
+            if m and keep(m.group(1)):
+                e = out.setdefault(m.group(1), {"FETCH_SIZE": [], "WRITE_SIZE": []})
+                e[c].append(float(r["Counter_Value"]) * 1024 * mult)
+    res = {}
+    for k, e in out.items():
+        rd, wr = sum(e["FETCH_SIZE"]) / max(len(e["FETCH_SIZE"]), 1), sum(e["WRITE_SIZE"]) / max(len(e["WRITE_SIZE"]), 1)
+        res[k] = {"launches": len(e["FETCH_SIZE"]), "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr), "total_bytes_per_launch": round(rd + wr)}
+    return res
+
+
+def sq(dirname, keep, res):
+    path = find(dirname, "SQ")
+    if not path:
+        return
+    acc = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        m = PAT.search(r["Kernel_Name"])
+        if m and keep(m.group(1)):
+            e = acc.setdefault(m.group(1), collections.defaultdict(list))
             e[r["Counter_Name"]].append(float(r["Counter_Value"]))
             e["_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
-    for k, e in sq.items():
+    for k, e in acc.items():
         avg = lambda c: sum(e[c]) / max(len(e[c]), 1)
         cyc = avg("GRBM_GUI_ACTIVE") / 8.0
         res.setdefault(k, {}).update({
@@ -39,7 +59,26 @@ if os.path.isfile(sq_path):
             "avg_duration_ms_under_pmc": round(avg("_ns") * 1e-6, 4),
             "lds_bank_conflict_frac": round(avg("SQ_LDS_BANK_CONFLICT") / avg("SQ_LDS_IDX_ACTIVE"), 4) if avg("SQ_LDS_IDX_ACTIVE") else 0.0,
             "valu_inst_per_mfma_busy_cycle": round(avg("SQ_ACTIVE_INST_VALU") / avg("SQ_VALU_MFMA_BUSY_CYCLES"), 3) if avg("SQ_VALU_MFMA_BUSY_CYCLES") else None})
-gl = [(v["launches"], v["total_bytes_per_launch"]) for k, v in res.items() if k.startswith("gemm")]
+
+
+is_lbs = lambda k: k.startswith("lbs_")
+lbs_dir = os.path.join(d, "lbs")
+have_lbs_dir = os.path.isdir(lbs_dir)
+res = traffic(d, (lambda k: not is_lbs(k)) if have_lbs_dir else (lambda k: True))
+sq(d, (lambda k: not is_lbs(k)) if have_lbs_dir else (lambda k: True), res)
+if have_lbs_dir:
+    r2 = traffic(lbs_dir, is_lbs)
+    sq(lbs_dir, is_lbs, r2)
+    for k, v in r2.items():
+        v["persons"] = 160
+    res.update(r2)
+gl = [(v["launches"], v["total_bytes_per_launch"]) for k, v in res.items() if k.startswith("gemm") and "launches" in v]
 if gl:
     res["_gemm_avg_bytes_per_launch"] = round(sum(n * b for n, b in gl) / sum(n for n, _ in gl))
+# one attention CALL = the main kernel + the (normally empty) fallback launch behind it
+al = sorted(((v["launches"], v["launches"] * v["total_bytes_per_launch"]) for k, v in res.items() if k.startswith("attn_kernel") and "launches" in v), reverse=True)
+if al:
+    res["_attention_bytes_per_call"] = round(sum(b for _, b in al) / al[0][0])
+with open(os.path.join(ROOT, "multi_hmr_amd", "csrc", "libmhmr.so"), "rb") as f:
+    res["_lib_sha16"] = hashlib.sha256(f.read()).hexdigest()[:16]
 print(json.dumps(res, indent=1))
