@@ -209,20 +209,20 @@ int mhmr_layernorm_f32(const float* in, const float* w, const float* b, float* o
  * roma.rotvec_to_rotmat (:107), inverse_perspective_projection (:117-123), perspective_projection (:143-144).
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct {
-    int V, Vp;            /* 10475, V rounded up to a multiple of 64                                         */
+    int V, Vp;            /* 10475, V rounded up to a multiple of 48 (the vertex kernel's tile)               */
     int Kb;               /* 486 + nb + 10 rounded up to a multiple of 32 (width of the feature rows F)        */
     int nb, Kinf;         /* num_betas, max skinning influences per vertex                                   */
     int center_joint;     /* JOINT_NAMES.index(person_center) = 15 ('head'); < 0 = person_center None: nothing is
                              recentred and the pelvis is added to the translation (smpl_layer.py:128-130)       */
-    const void* basis16;  /* f16 [Vp/16][Kb/8][2][3][16][8]: 1024 x [posedirs(486) | shapedirs(nb) | exprdirs(10)] as hi + lo,
-                             tile-major (the slice of a 16-vertex tile is one contiguous block)                   */
+    const void* basis16;  /* f16 [Vp/48][Kb/8][2][3][48][8]: 1024 x [posedirs(486) | shapedirs(nb) | exprdirs(10)] as hi + lo,
+                             tile-major (the slice of a 48-vertex tile is one contiguous block)                   */
     const float* vtemp;   /* [3][Vp]           v_template, fp32                                                */
     const float* J0;      /* [55*3]            J_regressor . v_template                                      */
     const float* JS;      /* [55*3][nb+10]     J_regressor . [shapedirs | exprdirs]                          */
     const int* parents;   /* [55]                                                                            */
     const int* skin_idx;  /* [V][Kinf]         K-sparse skinning list (kept for tools; the kernel reads skin16)        */
     const float* skin_w;  /* [V][Kinf]                                                                       */
-    const void* skin16;   /* f16 [Vp/16][8][2][16][8]: the DENSE skinning weights w[v][j] (joints 55..63 zero), hi + lo,
+    const void* skin16;   /* f16 [Vp/48][8][2][48][8]: the DENSE skinning weights w[v][j] (joints 55..63 zero), hi + lo,
                              j = 8 * block + lane-local index: the B operand of the skinning GEMM            */
     const int* extra_vid; /* [21]              vertex ids of joints 55..75                                   */
     const int* lmk_vidx;  /* [51*3]            faces[lmk_faces_idx]                                          */

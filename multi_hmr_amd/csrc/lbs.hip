@@ -9,19 +9,19 @@
 //       A16   component c of the folded transform [R0 R_w | R0 (t' - pelvis)] of joint j (joints 55..63 zero)
 //     (fragment-major: one 1 KiB block per (person group, part, k step), see the kernel)
 //  2. lbs_vertex_kernel (the HBM-bound one; algorithmic bytes = blend basis 64.5 MB + skin weights 2.7 MB once, 214 KB per person out)
-//     One workgroup = one 16-vertex tile for ALL persons: the tile's slice of the blend basis D = [posedirs ; shapedirs ; exprdirs]
-//     (x 2^10, f16 hi + lo, 98 KB) is DMA'd into LDS once -- HBM sees every basis byte exactly once per launch -- and wave g
-//     works on person group g (16 persons; groups beyond the wave count loop).  Both contractions run on the 16-bit matrix pipe at
-//     fp32 accuracy (x . y = xh.yh + xl.yh + xh.yl, fp32 accumulate; the dropped xl.yl term is 2^-22 relative):
-//       v_posed = v_template + F . D                      16 k-steps x 3 axes x 3 products   (B operand from LDS)
-//       T       = sum_j w[v][j] [R | t]_j  (12 numbers)    2 k-steps x 12 components x 3 products: the skinning blend as a GEMM over
-//                 the DENSE 64 x V weight matrix -- no per-vertex index list, no gathers of joint transforms (they were 17 us of
-//                 the previous kernel's 74 us at 160 persons, 322 MB through the L1)
+//     One workgroup = one 48-vertex tile for ALL persons of the launch: the tile's slice of the blend basis D = [posedirs ; shapedirs ;
+//     exprdirs] (x 2^10, f16 hi + lo, 288 KiB) streams through an LDS ring exactly once -- HBM sees every basis byte once per launch --
+//     and compute wave g works on person group g (16 persons).  Both contractions run on the 16-bit matrix pipe at fp32 accuracy
+//     (x . y = xh.yh + xl.yh + xh.yl, fp32 accumulate; the dropped xl.yl term is 2^-22 relative):
+//       v_posed = v_template + F . D                      16 k-steps x 3 vertex blocks x 3 axes x 3 products   (B operand from LDS)
+//       T       = sum_j w[v][j] [R | t]_j  (12 numbers)    2 k-steps x 12 components x 3 blocks x 3 products: the skinning blend as a
+//                 GEMM over the DENSE 64 x V weight matrix -- no per-vertex index list, no gathers of joint transforms
 //     Both land as (vertex = lane & 15, 4 persons per accumulator quad), so the rigid transform, the camera translation (added in
 //     fp32, exactly where the reference adds it: smpl_layer.py:139-140) and the pinhole projection are per-lane FMAs, and a lane
-//     stores its vertex as one 12-byte and one 8-byte access (16 lanes = 192 / 128 contiguous bytes per person).
-//     History at 160 persons: fp32 MFMA 108 us (matrix-bound), split-f16 blend + sparse gathered skinning 74 us (latency-bound K
-//     loop at ~2 waves per SIMD, basis re-read per 64-person slab), this kernel: see DESIGN.md section 5.
+//     stores its vertex as one 12-byte and one 8-byte access (16 lanes = 192 / 128 contiguous bytes per person and block).
+//     History at 160 persons: fp32 MFMA 108 us (matrix-bound); split-f16 blend + sparse gathered skinning 74 us; 16-vertex tiles with
+//     the skinning as a GEMM 54.7 us, with explicit operand prefetch 48.6 us (both bound by the vector-memory path feeding the A
+//     operands, see the kernel); this form 31.4 us (matrix pipe ~55 % busy on the 219 CUs that hold a tile).
 //  3. lbs_extra_joints_kernel  the 21 vertex-picked joints and 51 barycentric face landmarks.
 #include "mhmr_common.h"
 #include "mhmr_internal.h"
@@ -65,6 +65,7 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
                                                       float* __restrict__ j3d, float* __restrict__ j2d,
                                                       float* __restrict__ transl_out) {
     __shared__ float sR[NJ][9], sJ[NJ][3], sRw[NJ][9], sTw[NJ][3], sX[33];
+    __shared__ int sPar[NJ];
     const int p = blockIdx.x, j = threadIdx.x;
     // Both operands are stored FRAGMENT-MAJOR: the 64 lanes of a wave read one (person group, part, k step) fragment as 1 KiB of
     // consecutive bytes (16 B per lane, lane = 16 * (k group) + person-in-group), i.e. eight whole 128-byte lines per wave
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
         return;
     }
     const int ncoef = c.nb + 10;
+    if (j < NJ) sPar[j] = c.parents[j];
     if (j < NJ) {
         // full_pose (55) from the reference's 53-vector (smpl_layer.py:88-101): 0 -> zero (root applied after LBS),
         // 1..21 body, 22 jaw <- 52, 23/24 eyes zero, 25..39 left hand <- 22..36, 40..54 right hand <- 37..51
@@ -106,7 +108,9 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
         const float a0 = v0 + 1e-8f, a1 = v1 + 1e-8f, a2 = v2 + 1e-8f;
         const float angle = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
         const float rx = v0 / angle, ry = v1 / angle, rz = v2 / angle;
-        const float sn = sinf(angle), cs = cosf(angle), omc = 1.f - cs;
+        float sn, cs;
+        sincosf(angle, &sn, &cs);
+        const float omc = 1.f - cs;
         const float Km[9] = {0.f, -rz, ry, rz, 0.f, -rx, -ry, rx, 0.f};
         float KK[9];
         mat3_mul(Km, Km, KK);
@@ -117,15 +121,60 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
             sR[j][e] = r;
             if (j >= 1) put_f((j - 1) * 9 + e, r - id);
         }
-        // joints from the pre-contracted regressor
+        // joints from the pre-contracted regressor.  The usual 10 betas + 10 expression coefficients: the joint's three rows of JS are
+        // 15 independent 16-byte loads (a run-time loop of dependent scalar loads was most of this kernel's 15 us)
+        if (ncoef == 20) {
+            const f32x4* js = (const f32x4*)(c.JS + (size_t)(j * 3) * 20);
+            f32x4 row[15];
+#pragma unroll
+            for (int i = 0; i < 15; ++i) row[i] = js[i];
+            float cf[20];
+#pragma unroll
+            for (int l = 0; l < 10; ++l) { cf[l] = betas[(size_t)p * 10 + l]; cf[10 + l] = expr[(size_t)p * 10 + l]; }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float s = c.J0[j * 3 + a];
+#pragma unroll
+                for (int l = 0; l < 20; ++l) s += row[5 * a + (l >> 2)][l & 3] * cf[l];     // (same order of additions as the loop below)
+                sJ[j][a] = s;
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float s = c.J0[j * 3 + a];
+                const float* js = c.JS + (size_t)(j * 3 + a) * ncoef;
+                for (int l = 0; l < c.nb; ++l) s += js[l] * betas[(size_t)p * c.nb + l];
+                for (int l = 0; l < 10; ++l) s += js[c.nb + l] * expr[(size_t)p * 10 + l];
+                sJ[j][a] = s;
+            }
+        }
+    }
+    if (j == 63) {
+        // (an otherwise idle lane, beside the Rodrigues / joint-regression work of the others: these loads and the sin / cos no longer
+        // sit behind the kinematic chain)  root orientation (roma.rotvec_to_rotmat), translation (inverse_perspective_projection)
+        const float* rv = rotvec + (size_t)p * 53 * 3;
+        const float th = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+        const float den = fmaxf(th, 1e-6f);
+        const float kx = rv[0] / den, ky = rv[1] / den, kz = rv[2] / den;
+        float sn, cs;
+        sincosf(th, &sn, &cs);
+        const float omc = 1.f - cs;
+        const float xs = kx * sn, ys = ky * sn, zs = kz * sn;
+        const float xyc = kx * ky * omc, xzc = kx * kz * omc, yzc = ky * kz * omc;
+        const float xxc = kx * kx * omc, yyc = ky * ky * omc, zzc = kz * kz * omc;
+        const float R0[9] = {1.f - yyc - zzc, xyc - zs, xzc + ys, xyc + zs, 1.f - xxc - zzc, -xs + yzc, xzc - ys, xs + yzc, 1.f - xxc - yyc};
+        const float* Kp = Kmat + (size_t)det_b[p] * 9;
+        float Ki[9];
+        inv3x3(Kp, Ki);
+        const float lx = loc[2 * p], ly = loc[2 * p + 1], d = dist[p];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            float s = c.J0[j * 3 + a];
-            const float* js = c.JS + (size_t)(j * 3 + a) * ncoef;
-            for (int l = 0; l < c.nb; ++l) s += js[l] * betas[(size_t)p * c.nb + l];
-            for (int l = 0; l < 10; ++l) s += js[c.nb + l] * expr[(size_t)p * 10 + l];
-            sJ[j][a] = s;
+            const float tr = (Ki[a * 3] * lx + Ki[a * 3 + 1] * ly + Ki[a * 3 + 2] * 1.0f) * d;
+            sX[24 + a] = tr;
+            transl_out[3 * p + a] = tr;
         }
+#pragma unroll
+        for (int e = 0; e < 9; ++e) { sX[e] = R0[e]; sX[15 + e] = Kp[e]; }
     }
     // feature tail: [betas | expr | 0...]   (the template is added in fp32 by the vertex kernel)
     for (int k = 486 + j; k < c.Kb; k += 64) {
@@ -141,7 +190,7 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
     // small person counts)
     int depth = 0;
     if (j < NJ)
-        for (int a = c.parents[j]; a >= 0; a = c.parents[a]) ++depth;
+        for (int a = sPar[j]; a >= 0; a = sPar[a]) ++depth;          // (LDS: a chain of up to ten dependent GLOBAL loads cost 2 us)
     if (j == 0) {
 #pragma unroll
         for (int e = 0; e < 9; ++e) sRw[0][e] = sR[0][e];
@@ -154,7 +203,7 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
     for (int level = 1; level <= maxdepth; ++level) {
         __syncthreads();
         if (j < NJ && depth == level) {
-            const int pa = c.parents[j];
+            const int pa = sPar[j];
             float Rp[9], Rl[9], Rn[9], rel[3], t[3];
 #pragma unroll
             for (int e = 0; e < 9; ++e) { Rp[e] = sRw[pa][e]; Rl[e] = sR[j][e]; }
@@ -170,26 +219,11 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
     }
     __syncthreads();
     if (j == 0) {
-        // root orientation (roma.rotvec_to_rotmat), translation (inverse_perspective_projection), recentring
-        const float* rv = rotvec + (size_t)p * 53 * 3;
-        const float th = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
-        const float den = fmaxf(th, 1e-6f);
-        const float kx = rv[0] / den, ky = rv[1] / den, kz = rv[2] / den;
-        const float sn = sinf(th), cs = cosf(th), omc = 1.f - cs;
-        const float xs = kx * sn, ys = ky * sn, zs = kz * sn;
-        const float xyc = kx * ky * omc, xzc = kx * kz * omc, yzc = ky * kz * omc;
-        const float xxc = kx * kx * omc, yyc = ky * ky * omc, zzc = kz * kz * omc;
-        float R0[9] = {1.f - yyc - zzc, xyc - zs, xzc + ys, xyc + zs, 1.f - xxc - zzc, -xs + yzc, xzc - ys, xs + yzc, 1.f - xxc - yyc};
-        const float* Kp = Kmat + (size_t)det_b[p] * 9;
-        float Ki[9];
-        inv3x3(Kp, Ki);
-        const float lx = loc[2 * p], ly = loc[2 * p + 1], d = dist[p];
-        float tr[3];
+        // recentring.  person_center joint given: recentre on it (smpl_layer.py:131-136); None (center_joint < 0): the pelvis is ADDED
+        // to the translation instead and nothing is recentred (smpl_layer.py:128-130), i.e. o = tr + pelvis
+        float R0[9], cc[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) tr[a] = (Ki[a * 3] * lx + Ki[a * 3 + 1] * ly + Ki[a * 3 + 2] * 1.0f) * d;
-        // person_center joint given: recentre on it (smpl_layer.py:131-136); None (center_joint < 0): the pelvis is ADDED to the
-        // translation instead and nothing is recentred (smpl_layer.py:128-130), i.e. o = tr + pelvis
-        float cc[3];
+        for (int e = 0; e < 9; ++e) R0[e] = sX[e];
         if (c.center_joint >= 0) {
             float hc[3] = {sTw[c.center_joint][0] - sTw[0][0], sTw[c.center_joint][1] - sTw[0][1], sTw[c.center_joint][2] - sTw[0][2]};
             mat3_vec(R0, hc, cc);
@@ -198,11 +232,7 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
             for (int a = 0; a < 3; ++a) cc[a] = -sTw[0][a];
         }
 #pragma unroll
-        for (int e = 0; e < 9; ++e) sX[e] = R0[e];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { sX[9 + a] = sTw[0][a]; sX[12 + a] = tr[a] - cc[a]; transl_out[3 * p + a] = tr[a]; }
-#pragma unroll
-        for (int e = 0; e < 9; ++e) sX[15 + e] = Kp[e];
+        for (int a = 0; a < 3; ++a) { sX[9 + a] = sTw[0][a]; sX[12 + a] = sX[24 + a] - cc[a]; }
     }
     __syncthreads();
     if (j < 24) xf[(size_t)p * 24 + j] = sX[j];
@@ -239,147 +269,265 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
     }
 }
 
-// grid = Vp / 16 workgroups (one 16-vertex tile each) of LBS_NW waves; wave w works on person groups w and w + LBS_NW (two per wave
-// at 160 persons).  The k range is consumed in LBS_NQ quarters through TWO LDS buffers of one quarter of the tile's basis slice
-// ([Kb/32][hi|lo][3][16][8] f16 = 24 KiB each): quarter q + 1 is in flight while quarter q is multiplied, and three workgroups share
-// a CU.  (With one buffer and two halves every workgroup of the launch -- all 656 are resident at once -- waited for its DMA at the
-// same time and HBM idled during the MFMAs: 20.7 us at ONE person.)  A operands (F16, A16: L2-resident, identical for every vertex
-// tile) are ordinary loads issued a quarter ahead; they are requested AFTER the quarter's MFMAs and BEFORE the next barrier, so that
-// the one `s_waitcnt vmcnt(0)` per quarter (hipcc waits vmcnt(0) for an ordinary load beside LDS-DMA anyway) only ever waits for
-// things the next quarter needs.
+#ifdef MHMR_LBS_STAMPS      // tools/lbs_timeline.py: per-workgroup s_memtime stamps of wave 0 (debug build only, never in libmhmr.so)
+__device__ unsigned long long* g_lbs_stamps;
+#define LBS_STAMP(i)                                                                                           \
+    do {                                                                                                       \
+        if (g_lbs_stamps && threadIdx.x == 0) g_lbs_stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define LBS_STAMP(i)
+#endif
+// grid = Vp / 48 workgroups (one 48-vertex tile = three 16-vertex MFMA column blocks, for ALL persons of the launch) of
+// LBS_NC compute waves + LBS_NL loader waves; at most one workgroup per CU (126 KB of LDS).
+//   * loader waves do nothing but move the tile's slice of the blend basis (288 KiB) through a 3-slot LDS ring of k eighths
+//     (36 KiB each) with global_load_lds: two eighths are always in flight, so HBM never waits for a barrier; their vmcnt stream
+//     holds only these copies, so the landing wait is an exact count.  They also bring the persons' [R0 | translation | K]
+//     records into LDS once.
+//   * compute wave w owns person group g0 + w (16 persons).  Its A operands (F16, A16: L2-resident, the same for every tile) are
+//     ordinary loads one k step / one component ahead of their MFMAs; every loaded A fragment is multiplied against all THREE
+//     vertex blocks.  That reuse is the point of the 48-vertex tile: with 16-vertex tiles (three workgroups per CU, the previous
+//     form, 48.6 us at 160 persons) each fragment fed 9 MFMAs and the vector-memory path (64 B/clk per CU) moved 57 B/clk in the
+//     blend and 2.7x its peak in the skinning products -- tools/lbs_timeline.py showed 8 us per group for 1.9 us of MFMAs no
+//     matter how far ahead the loads were issued.  The B operands come from LDS one block ahead.
+// Both contractions keep fp32 accuracy on the 16-bit matrix pipe (x . y = xh.yh + xl.yh + xh.yl).
 struct __attribute__((packed, aligned(4))) Vec3 { float x, y, z; };
 struct __attribute__((packed, aligned(4))) Vec2 { float x, y; };
-constexpr int LBS_ROW = 16 * 8 * 2;          // bytes of one (k block, part, axis) row of the tile: 16 vertices x 8 k x f16
-constexpr int LBS_NW = 5, LBS_MAXG = 2;      // waves per workgroup; person groups a wave keeps accumulators for at once
-constexpr int LBS_NQ = 4;                    // k quarters
+constexpr int LBS_TV = 48, LBS_NST = LBS_TV / 16;      // vertices per tile, 16-vertex MFMA column blocks per tile
+constexpr int LBS_NC = 10, LBS_NL = 2;                 // compute waves (one person group each), loader waves
+constexpr int LBS_KB = 512;                            // padded blend depth (486 pose + betas + 10 expression <= 512)
+constexpr int LBS_NS = LBS_KB / 32;                    // k steps of 32
+constexpr int LBS_NE = 8, LBS_RING = 3;                // k eighths (2 steps each), LDS ring slots
+constexpr int LBS_ROW = LBS_TV * 8 * 2;                // bytes of one (k block, part, axis) row of the tile: 48 vertices x 8 k x f16
+constexpr int LBS_EBYTES = (LBS_KB / 8 / LBS_NE) * 6 * LBS_ROW;       // one eighth of the tile's slice: 36 KiB
+constexpr int LBS_EOPS = LBS_EBYTES / 1024 / LBS_NL;                  // 1-KiB copies per loader wave per eighth
+constexpr int LBS_WBYTES = 8 * 2 * LBS_TV * 8 * 2;     // the tile's dense skin weights, hi + lo: 12 KiB
+constexpr int LBS_XREC = 24 * 4;                       // bytes of one person's record in ws_xf
+constexpr int LBS_LDS = LBS_RING * LBS_EBYTES + LBS_NC * 16 * LBS_XREC;
+static_assert(LBS_EBYTES % (1024 * LBS_NL) == 0 && LBS_EOPS == 18 && LBS_WBYTES / 1024 / LBS_NL == 6 && (LBS_RING == 3 || LBS_RING == 4),
+              "the landing waits below are written for 18 copies per wave and eighth, 6 for the weights, 1 or 2 eighths ahead");
+static_assert(LBS_LDS <= 160 * 1024, "LDS");
 
-__global__ __launch_bounds__(64 * LBS_NW, 4) void lbs_vertex_kernel(const mhmr_lbs_consts c, const _Float16* __restrict__ F16,
-                                                                    const _Float16* __restrict__ A16, const float* __restrict__ xf, int P,
-                                                                    int Pp, int g0, float* __restrict__ v3d, float* __restrict__ v2d) {
-    typedef Op<MHMR_DT_F16>::V8 H8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void lbs_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// loader wave lw: the tile's basis slice, eighth by eighth, + the person records
+__device__ __forceinline__ void lbs_loader(const mhmr_lbs_consts& c, const float* __restrict__ xf, int P, int ngroups, int g0, char* smem,
+                                           int lw) {
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g4 = lane >> 4, l15 = lane & 15;
-    const int v0 = blockIdx.x * 16;
-    const int ns = c.Kb / 32, nsq = ns / LBS_NQ;                    // k-steps of 32, per quarter (4 at Kb = 512)
-    const int rows_q = (c.Kb / 8 / LBS_NQ) * 6;                     // (k block, part, axis) rows of one quarter (96 at Kb = 512)
-    const int ngroups = Pp / 16;
-
-    // one quarter of the tile's basis slice -> LDS buffer `buf`: a wave instruction moves 1 KiB (4 rows of 16 vertices x 16 B), source and
-    // LDS image both lane-linear (tile-major basis: the tile's slice is one contiguous block)
-    const _Float16* bsrc = (const _Float16*)c.basis16 + (size_t)blockIdx.x * (LBS_NQ * rows_q * 128) + lane * 8;
-    auto dma_q = [&](int q, int buf) {
-        for (int i = w; i < rows_q / 4; i += LBS_NW)
-            glds16(bsrc + (size_t)(q * rows_q + 4 * i) * 128, smem + buf * (rows_q * LBS_ROW) + i * (4 * LBS_ROW));
-    };
-    // this wave's A operands of quarter q (fragment-major: 1 KiB per (group, part, k step))
-    H8 ah[LBS_MAXG][4], al[LBS_MAXG][4];
-    auto load_f = [&](int q) {
+    char* xrec = smem + LBS_RING * LBS_EBYTES;
+    for (int i = lw; i < LBS_NC; i += LBS_NL) {
+        const int g = g0 + i;
+        if (g >= ngroups) break;
+        const int bytes = min(16, P - 16 * g) * LBS_XREC;
+        const char* src = (const char*)(xf + (size_t)g * 16 * 24) + lane * 16;
 #pragma unroll
-        for (int i = 0; i < LBS_MAXG; ++i) {
-            const int g = g0 + w + i * LBS_NW;
-            if (g < ngroups) {
-                const _Float16* fh = F16 + ((((size_t)g * 2) * ns + q * nsq) * 64 + lane) * 8;
-                const _Float16* fl = fh + (size_t)ns * 512;
+        for (int k = 0; k < 2; ++k)
+            if (k * 1024 + lane * 16 < bytes) glds16(src + k * 1024, xrec + i * (16 * LBS_XREC) + k * 1024);
+    }
+    // tile-major basis: the tile's slice is one contiguous block, an eighth is 36 consecutive KiB; source and LDS image lane-linear
+    const _Float16* bsrc = (const _Float16*)c.basis16 + (size_t)blockIdx.x * (LBS_NE * LBS_EBYTES / 2) + lane * 8;
+    auto dma_e = [&](int e) {
+        char* dst = smem + (e % LBS_RING) * LBS_EBYTES;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    if (s < nsq) { ah[i][s] = *(const H8*)(fh + 512 * s); al[i][s] = *(const H8*)(fl + 512 * s); }
-                }
-            }
+        for (int k = 0; k < LBS_EOPS; ++k) {
+            const int i = lw * LBS_EOPS + k;
+            glds16(bsrc + (size_t)e * (LBS_EBYTES / 2) + i * 512, dst + i * 1024);
         }
     };
-    dma_q(0, 0);
-    load_f(0);
-    // dense skin weights of the tile (B operand of the skinning GEMM): lane (v = l15, k group g4) holds joints 8 (4 t + g4) + 0..7
-    H8 wh[2], wl[2];
-    {
-        const _Float16* wp = (const _Float16*)c.skin16 + (size_t)blockIdx.x * (8 * 2 * 128) + l15 * 8;      // tile-major [8][hi|lo][16][8]
+#pragma unroll
+    for (int e = 0; e < LBS_RING - 1; ++e) dma_e(e);
+    constexpr int EW = LBS_NE - LBS_RING + 1;            // the eighth at whose top the weights are requested (its slot: no later eighth's)
+    constexpr int WOPS = LBS_WBYTES / 1024 / LBS_NL;
+#pragma unroll
+    for (int e = 0; e < LBS_NE; ++e) {
+        // eighth e (and everything older: the records) has landed when at most the copies requested after it are outstanding:
+        // the up to LBS_RING - 2 following eighths and, once requested, the weights
+        const int younger = LBS_EOPS * (min(LBS_NE - 1, e + LBS_RING - 2) - e) + (e > EW ? WOPS : 0);
+        if (younger == 36) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+        else if (younger == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (younger == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lbs_barrier();                                   // ... and every compute wave is done with eighth e - 1: its slot is free
+        if (e + LBS_RING - 1 < LBS_NE) dma_e(e + LBS_RING - 1);
+        else if (e == EW) {
+            // the tile's dense skin weights (12 KiB, tile-major [8 joint blocks][hi|lo][48][8] = MFMA operand order) take the slot no
+            // further eighth needs; the last landing wait (vmcnt(0)) and barrier publish them together with eighth 7
+            const _Float16* wsrc = (const _Float16*)c.skin16 + (size_t)blockIdx.x * (LBS_WBYTES / 2) + lane * 8;
+            char* dst = smem + (LBS_NE % LBS_RING) * LBS_EBYTES;
+#pragma unroll
+            for (int k = 0; k < WOPS; ++k) {
+                const int i = lw * WOPS + k;
+                glds16(wsrc + i * 512, dst + i * 1024);
+            }
+        }
+    }
+}
+
+// compute wave: person group g (16 persons) against the tile's 48 vertices
+__device__ __forceinline__ void lbs_compute(const mhmr_lbs_consts& c, const _Float16* __restrict__ F16, const _Float16* __restrict__ A16,
+                                            int P, int ngroups, int g, int w, float* __restrict__ v3d, float* __restrict__ v2d,
+                                            const char* smem) {
+    typedef Op<MHMR_DT_F16>::V8 H8;
+    const int lane = threadIdx.x & 63;
+    const int g4 = lane >> 4, l15 = lane & 15;
+    const int v0 = blockIdx.x * LBS_TV;
+
+    // A operands of k step sg (fragment-major: 1 KiB per (group, part, k step)), [set][hi | lo]
+    H8 A[2][2];
+    auto load_a = [&](int set, int sg) {
+        const _Float16* fh = F16 + ((((size_t)g * 2) * LBS_NS + sg) * 64 + lane) * 8;
+        A[set][0] = *(const H8*)fh;
+        A[set][1] = *(const H8*)(fh + (size_t)LBS_NS * 512);
+    };
+    // skinning operands of component cmp: [set][xh t0, xh t1, xl t0, xl t1]
+    H8 X[2][4];
+    const size_t part = (size_t)ngroups * 1024;
+    auto load_x = [&](int set, int cmp) {
+        const _Float16* ap = A16 + ((size_t)g * 2 * 64 + lane) * 8 + (size_t)(2 * cmp) * part;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            wh[t] = *(const H8*)(wp + ((4 * t + g4) * 2 + 0) * 128);
-            wl[t] = *(const H8*)(wp + ((4 * t + g4) * 2 + 1) * 128);
+            X[set][t] = *(const H8*)(ap + 512 * t);
+            X[set][2 + t] = *(const H8*)(ap + part + 512 * t);
         }
-    }
-    const int v = v0 + l15;
-    const bool vok = v < c.V;
-    const float vt0 = vok ? c.vtemp[v] : 0.f, vt1 = vok ? c.vtemp[c.Vp + v] : 0.f, vt2 = vok ? c.vtemp[2 * c.Vp + v] : 0.f;   // fp32 template
+    };
 
-    f32x4 acc[LBS_MAXG][3];
+    load_a(0, 0);
+    f32x4 acc[LBS_NST][3];
 #pragma unroll
-    for (int i = 0; i < LBS_MAXG; ++i)
+    for (int st = 0; st < LBS_NST; ++st)
 #pragma unroll
-        for (int a = 0; a < 3; ++a) acc[i][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < 3; ++a) acc[st][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ---- v_posed - v_template = F . D ----
-    for (int q = 0; q < LBS_NQ; ++q) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // quarter q's DMA (hipcc does not wait for LDS-DMA by itself) and A operands
-        __syncthreads();                                            // ... of every wave; and everyone is done reading the other buffer
 #pragma unroll
-        for (int i = 0; i < LBS_MAXG; ++i)                          // (pins the compiler's own wait for the A operands in front of the DMA)
+    for (int e = 0; e < LBS_NE; ++e) {
+        lbs_barrier();
+        LBS_STAMP(1 + e);
+        const char* slot = smem + (e % LBS_RING) * LBS_EBYTES + g4 * (6 * LBS_ROW) + l15 * 16;     // + (4 s2) * 6 rows + (part * 3 + axis) rows + st * 256
+        H8 B[2][6];
+        auto read_b = [&](int set, int j) {           // j = 3 * s2 + st: the six (part, axis) fragments of one vertex block of one k step
+            const char* b = slot + (j / 3) * (24 * LBS_ROW) + (j % 3) * 256;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(ah[i][s]), "+v"(al[i][s]));
-        if (q + 1 < LBS_NQ) dma_q(q + 1, (q + 1) & 1);
-        const char* brow = smem + (q & 1) * (rows_q * LBS_ROW) + g4 * (6 * LBS_ROW) + l15 * 16;   // + s * 24 rows + (part * 3 + axis) rows
+            for (int k = 0; k < 6; ++k) B[set][k] = *(const H8*)(b + k * LBS_ROW);
+        };
+        read_b(0, 0);
 #pragma unroll
-        for (int i = 0; i < LBS_MAXG; ++i) {
-            if (g0 + w + i * LBS_NW < ngroups) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    if (s < nsq) {
-                        const char* bs = brow + (size_t)s * (24 * LBS_ROW);
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) {
-                            const H8 bh = *(const H8*)(bs + a * LBS_ROW), bl = *(const H8*)(bs + (3 + a) * LBS_ROW);
-                            acc[i][a] = Op<MHMR_DT_F16>::mfma16(ah[i][s], bh, acc[i][a]);
-                            acc[i][a] = Op<MHMR_DT_F16>::mfma16(al[i][s], bh, acc[i][a]);
-                            acc[i][a] = Op<MHMR_DT_F16>::mfma16(ah[i][s], bl, acc[i][a]);
-                        }
-                    }
-                }
+        for (int j = 0; j < 6; ++j) {
+            const int s2 = j / 3, st = j % 3, sg = 2 * e + s2;
+            if (st == 0) {
+                if (sg + 1 < LBS_NS) load_a((sg + 1) & 1, sg + 1);
+                else load_x(0, 0);                        // the last step: the skinning phase's first operands
             }
+            if (j + 1 < 6) read_b((j + 1) & 1, j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int prod = 0; prod < 3; ++prod)
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    acc[st][a] = Op<MHMR_DT_F16>::mfma16(A[sg & 1][prod == 1 ? 1 : 0], B[j & 1][prod == 2 ? 3 + a : a], acc[st][a]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (q + 1 < LBS_NQ) load_f(q + 1);
     }
-    // (no early exit for the padding vertices of the last tile: a lane is a vertex COLUMN of the products but a person ROW of the A
-    // operands, so every lane stays active through the MFMAs; only the stores are guarded)
-    // ---- T = sum_j w[v][j] [R | t]_j (one accumulator per component), rigid transform, camera translation, projection, stores ----
+    LBS_STAMP(9);
+    // (no early exit for padding vertices / persons: a lane is a vertex COLUMN of the products but a person ROW of the A operands,
+    // so every lane stays active through the MFMAs; only the stores are guarded)
+    // ---- T = sum_j w[v][j] [R | t]_j component by component, folded into the rigid transform as it arrives ----
+    float o3[LBS_NST][3][4];
 #pragma unroll
-    for (int i = 0; i < LBS_MAXG; ++i) {
-        const int g = g0 + w + i * LBS_NW;
-        if (g >= ngroups) break;
-        const int pg = 16 * g;
-        const _Float16* ap = A16 + ((size_t)g * 2 * 64 + lane) * 8;       // + ((2 cmp + part) * ngroups * 2 + t) * 512
-        const size_t part = (size_t)ngroups * 1024;
-        f32x4 T[12];
+    for (int st = 0; st < LBS_NST; ++st) {
+        const int v = v0 + 16 * st + l15;                                                 // < Vp: the template is padded with zeros
 #pragma unroll
-        for (int cmp = 0; cmp < 12; ++cmp) {
-            T[cmp] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < 3; ++a) {
+            const float vt = c.vtemp[a * c.Vp + v];                                      // fp32 template
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[st][a][r] = acc[st][a][r] * (1.0f / 1024.0f) + vt;
+        }
+    }
+    // B operand of the skinning GEMM = the tile's dense skin weights, from LDS (loader): lane (v = l15, k group g4) of vertex block st
+    // holds joints 8 (4 t + g4) + 0..7; [set][wh t0, wh t1, wl t0, wl t1], one block ahead
+    const char* wlds = smem + (LBS_NE % LBS_RING) * LBS_EBYTES + g4 * (2 * LBS_ROW) + l15 * 16;
+    H8 W[2][4];
+    auto read_w = [&](int set, int st) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            W[set][t] = *(const H8*)(wlds + (4 * t) * (2 * LBS_ROW) + st * 256);
+            W[set][2 + t] = *(const H8*)(wlds + (4 * t) * (2 * LBS_ROW) + LBS_ROW + st * 256);
+        }
+    };
+    read_w(0, 0);
+#pragma unroll
+    for (int cmp = 0; cmp < 12; ++cmp) {
+        if (cmp + 1 < 12) load_x((cmp + 1) & 1, cmp + 1);
+        const H8* x = X[cmp & 1];
+        const int a = cmp >> 2, k = cmp & 3;
+#pragma unroll
+        for (int st = 0; st < LBS_NST; ++st) {
+            const int j = cmp * LBS_NST + st;
+            if (j + 1 < 12 * LBS_NST) read_w((j + 1) & 1, (st + 1) % LBS_NST);
+            __builtin_amdgcn_sched_barrier(0);
+            const H8* wf = W[j & 1];
+            f32x4 T = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const H8 xh = *(const H8*)(ap + (size_t)(2 * cmp) * part + 512 * t), xl = *(const H8*)(ap + (size_t)(2 * cmp + 1) * part + 512 * t);
-                T[cmp] = Op<MHMR_DT_F16>::mfma16(xh, wh[t], T[cmp]);
-                T[cmp] = Op<MHMR_DT_F16>::mfma16(xl, wh[t], T[cmp]);
-                T[cmp] = Op<MHMR_DT_F16>::mfma16(xh, wl[t], T[cmp]);
+                T = Op<MHMR_DT_F16>::mfma16(x[t], wf[t], T);
+                T = Op<MHMR_DT_F16>::mfma16(x[2 + t], wf[t], T);
+                T = Op<MHMR_DT_F16>::mfma16(x[t], wf[2 + t], T);
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (k == 0) o3[st][a][r] = T[r] * acc[st][0][r];
+                else if (k == 1) o3[st][a][r] += T[r] * acc[st][1][r];
+                else if (k == 2) o3[st][a][r] += T[r] * acc[st][2][r];
+                else o3[st][a][r] += T[r];
+                asm volatile("" : "+v"(o3[st][a][r]));      // fold HERE: LLVM otherwise sinks these FMAs into the guarded store blocks
+            }                                               // below and keeps all 36 products alive (340 B of scratch per lane)
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    LBS_STAMP(10);
+    // ---- camera translation (fp32, exactly where the reference adds it: smpl_layer.py:139-140), projection, stores ----
+    const char* xrec = smem + LBS_RING * LBS_EBYTES + w * (16 * LBS_XREC);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int p = pg + 4 * g4 + r;
-            if (p >= P || !vok) continue;
-            const float vx = acc[i][0][r] * (1.0f / 1024.0f) + vt0, vy = acc[i][1][r] * (1.0f / 1024.0f) + vt1,
-                        vz = acc[i][2][r] * (1.0f / 1024.0f) + vt2;
-            const f32x4* X = (const f32x4*)(xf + (size_t)p * 24 + 12);             // [o (3), K (9)]: three 16-byte loads
-            const f32x4 x0 = X[0], x1 = X[1], x2 = X[2];
-            float o3[3];
+    for (int r = 0; r < 4; ++r) {
+        const int p = 16 * g + 4 * g4 + r;
+        if (p >= P) continue;
+        const f32x4* Xr = (const f32x4*)(xrec + (4 * g4 + r) * LBS_XREC + 48);      // [o (3), K (9)]
+        const f32x4 x0 = Xr[0], x1 = Xr[1], x2 = Xr[2];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) o3[a] = T[4 * a][r] * vx + T[4 * a + 1][r] * vy + T[4 * a + 2][r] * vz + T[4 * a + 3][r] + x0[a];
-            *(Vec3*)(v3d + ((size_t)p * c.V + v) * 3) = Vec3{o3[0], o3[1], o3[2]};          // one 12-byte store (dword-aligned)
+        for (int st = 0; st < LBS_NST; ++st) {
+            const int v = v0 + 16 * st + l15;
+            if (v >= c.V) continue;
+            const float ox = o3[st][0][r] + x0[0], oy = o3[st][1][r] + x0[1], oz = o3[st][2][r] + x0[2];
+            *(Vec3*)(v3d + ((size_t)p * c.V + v) * 3) = Vec3{ox, oy, oz};          // one 12-byte store (dword-aligned)
             // perspective_projection (utils/camera.py:14-27) with one reciprocal instead of three divisions (<= 1 ulp apart)
-            const float iz = __builtin_amdgcn_rcpf(o3[2]);
-            const float yx = o3[0] * iz, yy = o3[1] * iz, yz = o3[2] * iz;
+            const float iz = __builtin_amdgcn_rcpf(oz);
+            const float yx = ox * iz, yy = oy * iz, yz = oz * iz;
             *(Vec2*)(v2d + ((size_t)p * c.V + v) * 2) = Vec2{x0[3] * yx + x1[0] * yy + x1[1] * yz, x1[2] * yx + x1[3] * yy + x2[0] * yz};
         }
+    }
+    LBS_STAMP(11);
+}
+
+__global__ __launch_bounds__(64 * (LBS_NC + LBS_NL), 3) void lbs_vertex_kernel(const mhmr_lbs_consts c, const _Float16* __restrict__ F16,
+                                                                               const _Float16* __restrict__ A16, const float* __restrict__ xf,
+                                                                               int P, int Pp, int g0, float* __restrict__ v3d,
+                                                                               float* __restrict__ v2d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ngroups = Pp / 16;
+    LBS_STAMP(0);
+    // every wave passes the same LBS_NE barriers
+    if (w >= LBS_NC) {
+        lbs_loader(c, xf, P, ngroups, g0, smem, w - LBS_NC);
+    } else if (g0 + w < ngroups) {
+        lbs_compute(c, F16, A16, P, ngroups, g0 + w, w, v3d, v2d, smem);
+    } else {
+#pragma unroll
+        for (int e = 0; e < LBS_NE; ++e) lbs_barrier();
     }
 }
 
@@ -424,26 +572,34 @@ __global__ __launch_bounds__(128) void lbs_extra_joints_kernel(const mhmr_lbs_co
 
 }  // namespace
 
+#ifdef MHMR_LBS_STAMPS
+extern "C" int mhmr_debug_lbs_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lbs_stamps), &p, sizeof(p)); }
+#endif
+
 extern "C" int mhmr_lbs_forward(const mhmr_lbs_consts* c, const float* rotvec, const float* betas, const float* expr,
                                 const float* loc, const float* dist, const float* Kmat, const int* det_b, int P, float* ws_F,
                                 float* ws_A, float* ws_xf, float* v3d, float* v2d, float* j3d, float* j2d, float* transl,
                                 void* stream) {
     if (!c || P < 0) return MHMR_ERR_BAD_ARG;
     if (P == 0) return 0;
-    if (c->Kb % 32 || c->Vp % 64 || c->Kb < 486 + c->nb + 10 || !c->skin16) return MHMR_ERR_BAD_SHAPE;
+    if (c->Vp % LBS_TV || c->Vp < c->V || c->Kb != LBS_KB || c->Kb < 486 + c->nb + 10 || !c->skin16) return MHMR_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int Pp = (P + 15) / 16 * 16;
-    if (c->Kb % 128 || c->Kb > 512) return MHMR_ERR_BAD_SHAPE;     // four equal k quarters of at most 4 steps
-    const size_t lds = 2 * (size_t)(c->Kb / 32) * 6 * LBS_ROW;     // two buffers of one quarter of a tile's basis slice: 49152 B at Kb = 512
+    static bool lds_ok = false;                                       // 126 KB of dynamic LDS: above the default per-kernel limit
+    if (!lds_ok) {
+        hipError_t e = hipFuncSetAttribute((const void*)lbs_vertex_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LBS_LDS);
+        if (e != hipSuccess) return (int)e;
+        lds_ok = true;
+    }
     hipLaunchKernelGGL(lbs_pose_kernel, dim3(Pp), dim3(64), 0, s, *c, rotvec, betas, expr, loc, dist, Kmat, det_b, P, Pp,
                        (_Float16*)ws_F, (_Float16*)ws_A, ws_xf, j3d, j2d, transl);
     MHMR_CHECK_LAUNCH();
-    // one launch covers LBS_NW * LBS_MAXG = 10 person groups (160 persons); more persons take further launches over the same tiles
+    // one launch covers LBS_NC person groups (160 persons); more persons take further launches over the same tiles
     const int ngroups = Pp / 16;
     prof_begin(PROF_LBS, s);
-    for (int g0 = 0; g0 < ngroups; g0 += LBS_NW * LBS_MAXG)
-        hipLaunchKernelGGL(lbs_vertex_kernel, dim3(c->Vp / 16), dim3(64 * LBS_NW), lds, s, *c, (const _Float16*)ws_F, (const _Float16*)ws_A, ws_xf,
-                           P, Pp, g0, v3d, v2d);
+    for (int g0 = 0; g0 < ngroups; g0 += LBS_NC)
+        hipLaunchKernelGGL(lbs_vertex_kernel, dim3(c->Vp / LBS_TV), dim3(64 * (LBS_NC + LBS_NL)), LBS_LDS, s, *c, (const _Float16*)ws_F,
+                           (const _Float16*)ws_A, ws_xf, P, Pp, g0, v3d, v2d);
     prof_end(PROF_LBS, s, (double)P);
     MHMR_CHECK_LAUNCH();
     hipLaunchKernelGGL(lbs_extra_joints_kernel, dim3(P), dim3(128), 0, s, *c, v3d, v2d, ws_xf, j3d, j2d);

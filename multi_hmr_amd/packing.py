@@ -53,12 +53,16 @@ def interpolate_pos_embed(pos_embed: np.ndarray, G: int, offset: float = 0.1) ->
 
 
 # ---------------------------------------------------------------------------------------------- SMPL-X
+#: vertices per workgroup tile of the vertex kernel (csrc/lbs.hip LBS_TV)
+LBS_TILE = 48
+
+
 def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) -> dict:  # person_center_idx < 0: no recentring
     """SMPL-X arrays (keys of SMPLX_NEUTRAL.npz) -> mhmr_lbs_consts tensors.
 
     * blend basis rows = [posedirs (486) | shapedirs[:, :, :nb] | shapedirs[:, :, 300:310] | 0-pad], scaled by 2^10 into the f16
-      normal range and stored as an f16 pair hi + lo, tile-major [Vp/16][Kb/8][hi|lo][3][16][8]: one 16-byte line per lane is the
-      16x16x32 MFMA operand for 8 consecutive k; the template stays fp32 ([3][Vp]);
+      normal range and stored as an f16 pair hi + lo, tile-major [Vp/48][Kb/8][hi|lo][3][48][8] (48-vertex tiles = three MFMA
+      column blocks): one 16-byte line per lane is the 16x16x32 MFMA operand for 8 consecutive k; the template stays fp32 ([3][Vp]);
     * the dense joint regressor is pre-contracted with the template and the blend shapes (J = J0 + JS.coef);
     * skinning weights: the dense [64, Vp] matrix as an f16 pair hi + lo in MFMA operand order (``skin16``; the kernel blends the
       joint transforms as a GEMM), plus the K-sparse (index, weight) list, K = max non-zeros per vertex (tools / tests).
@@ -73,17 +77,18 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
     assert pd.shape[-1] == 486
     ncoef = num_betas + 10
     Kb = roundup(486 + ncoef, 32)
-    Vp = roundup(V, 64)
+    Vp = roundup(V, LBS_TILE)
     D = np.zeros((Kb, 3, Vp), dtype=np.float64)
     D[:486, :, :V] = pd.transpose(2, 1, 0)
     D[486:486 + ncoef, :, :V] = shp.transpose(2, 1, 0)
     Ds = (D * 1024.0).astype(np.float32)
     hi = Ds.astype(np.float16)
     lo = (Ds - hi.astype(np.float32)).astype(np.float16)
-    # tile-major: the slice of one 16-vertex tile is ONE contiguous 96 KiB block [Kb/8][hi|lo][3][16][8] (the kernel DMAs it into
-    # LDS in two halves: whole DRAM pages instead of 256-byte pieces 168 KB apart)
-    lay = lambda a: a.reshape(Kb // 8, 8, 3, Vp // 16, 16).transpose(3, 0, 2, 4, 1)         # [Vp/16, Kb/8, 3, 16, 8]
-    basis16 = np.ascontiguousarray(np.stack([lay(hi), lay(lo)], axis=2))                    # [Vp/16, Kb/8, 2, 3, 16, 8]
+    # tile-major: the slice of one 48-vertex tile is ONE contiguous 288 KiB block [Kb/8][hi|lo][3][48][8] (the kernel DMAs it into
+    # LDS an eighth at a time: whole DRAM pages instead of 768-byte pieces 168 KB apart)
+    T = LBS_TILE
+    lay = lambda a: a.reshape(Kb // 8, 8, 3, Vp // T, T).transpose(3, 0, 2, 4, 1)           # [Vp/48, Kb/8, 3, 48, 8]
+    basis16 = np.ascontiguousarray(np.stack([lay(hi), lay(lo)], axis=2))                    # [Vp/48, Kb/8, 2, 3, 48, 8]
     vtemp = np.zeros((3, Vp), dtype=np.float32)
     vtemp[:, :V] = v_t.T
 
@@ -103,8 +108,8 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
     Wd[: W.shape[1], :V] = W.T.astype(np.float32)
     whi = Wd.astype(np.float16)
     wlo = (Wd - whi.astype(np.float32)).astype(np.float16)
-    wlay = lambda a: a.reshape(8, 8, Vp // 16, 16).transpose(2, 0, 3, 1)                      # [Vp/16, 8, 16, 8]
-    skin16 = np.ascontiguousarray(np.stack([wlay(whi), wlay(wlo)], axis=2))                   # [Vp/16, 8, 2, 16, 8]
+    wlay = lambda a: a.reshape(8, 8, Vp // T, T).transpose(2, 0, 3, 1)                        # [Vp/48, 8, 48, 8]
+    skin16 = np.ascontiguousarray(np.stack([wlay(whi), wlay(wlo)], axis=2))                   # [Vp/48, 8, 2, 48, 8]
 
     parents = np.asarray(data["kintree_table"])[0].astype(np.int64).copy()
     parents[0] = -1

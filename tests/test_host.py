@@ -51,16 +51,16 @@ def test_pack_smplx_is_an_exact_refactoring_of_smplx_lbs(smplx_data):
     pf = 0.1 * torch.randn(486, generator=g)
     F = torch.zeros(pk["Kb"], dtype=torch.float64)
     F[:486], F[486:506] = pf.double(), coef.double()
-    b16 = pk["basis16"].double()                                                  # [Vp/16, Kb/8, hi|lo, axis, 16, 8], scaled by 2^10
+    b16 = pk["basis16"].double()                                                  # [Vp/48, Kb/8, hi|lo, axis, 48, 8], scaled by 2^10
     D = (b16[:, :, 0] + b16[:, :, 1]).permute(1, 4, 2, 0, 3).reshape(pk["Kb"], 3, pk["Vp"]) / 1024.0  # [k, axis, v]
     v_posed = (torch.einsum("k,kav->va", F, D) + pk["vtemp"].double().T)[: pk["V"]].float()
     assert float((D.float() - D.half().float()).abs().max()) > 0 and pk["basis16"].dtype == torch.float16      # hi alone would not do
     ref = v_shaped + (pf @ bm.posedirs).view(-1, 3)
     assert float((v_posed - ref).abs().max()) < 2e-6
-    assert pk["Kinf"] == 4 and pk["Vp"] % 64 == 0 and pk["Kb"] % 32 == 0
+    assert pk["Kinf"] == 4 and pk["Vp"] % 48 == 0 and pk["Kb"] % 32 == 0
     W = torch.zeros(pk["V"], 55).scatter_add_(1, pk["skin_idx"].long(), pk["skin_w"])
     assert torch.allclose(W, bm.lbs_weights, atol=0)
-    s16 = pk["skin16"].double()                                                   # dense [Vp/16, 8, hi|lo, 16, 8] = w[v][j], j = 8 * block + e
+    s16 = pk["skin16"].double()                                                   # dense [Vp/48, 8, hi|lo, 48, 8] = w[v][j], j = 8 * block + e
     Wd = (s16[:, :, 0] + s16[:, :, 1]).permute(0, 2, 1, 3).reshape(pk["Vp"], 64)
     assert float((Wd[: pk["V"], :55] - bm.lbs_weights.double()).abs().max()) < 1e-7 and float(Wd[:, 55:].abs().max()) == 0
     assert (pk["lmk_vidx"].numpy() == bm.faces[bm.lmk_faces_idx.numpy()]).all()

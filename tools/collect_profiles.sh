@@ -9,6 +9,8 @@ mkdir -p $OUT/pmc/lbs $OUT/trace
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --only-headline-kernels"
 LBS="python $R/tools/lbs_bench.py 160"
+# (a) the headline forward alone: per-kernel averages comparable with the bench line's avg_launch_ms; (b) the whole default command
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o headline --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --only-headline-kernels > $OUT/trace/headline.json 2> $OUT/trace/err_headline.txt
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/trace/bench.json 2> $OUT/trace/err.txt
 SQSET="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -19,7 +21,6 @@ rocprofv3 --kernel-trace --pmc $SQSET -d $OUT/pmc -o SQ --output-format csv -- $
 rocprofv3 --kernel-trace --pmc $SQSET -d $OUT/pmc/lbs -o SQ --output-format csv -- $LBS > /dev/null 2>&1
 cd $R
 python tools/pmc_traffic.py $OUT/pmc > $OUT/pmc.json 2> $OUT/pmc_err.txt
-find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 # keep the merge small: the raw per-dispatch csv files are large
 find $OUT -name "*_counter_collection.csv" -size +8M -delete
 find $OUT -name "*kernel_trace.csv" -delete

@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Where the SMPL-X vertex kernel's time goes: per-workgroup s_memtime stamps of wave 0 from a debug build of lbs.hip
+(-DMHMR_LBS_STAMPS, linked into tools/dbg/libmhmr_stamps.so; the product library carries no stamps).
+  stamp 0 start | 1..8 eighth e's basis slice landed (barrier passed) | 9 blend done | 10 skinning products folded | 11 stores issued
+usage: MHMR_LIB=tools/dbg/libmhmr_stamps.so python tools/lbs_timeline.py [P]"""
+import ctypes as C, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multi_hmr_amd import _lib, packing
+import synthetic
+lib = C.CDLL(os.path.abspath(os.environ["MHMR_LIB"]))
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 160
+dev = torch.device("cuda:0")
+lb = packing.pack_smplx(synthetic.make_smplx_data(0), 10, dev); cs = packing.lbs_consts_struct(lb)
+g = torch.Generator(device=dev).manual_seed(5)
+f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+pose = 0.3 * torch.randn(P, 53, 3, generator=g, device=dev)
+shape, expr = torch.randn(P, 10, generator=g, device=dev), torch.randn(P, 10, generator=g, device=dev)
+loc, dist = 1288 * torch.rand(P, 2, generator=g, device=dev), 2 + 6 * torch.rand(P, 1, generator=g, device=dev)
+K = synthetic.get_camera_K(1288, 8).to(dev); det_b = (torch.arange(P, device=dev, dtype=torch.int32) * 8 // P).contiguous()
+V = lb["V"]
+bufs = [f((P + 15) // 16 * 16, lb["Kb"]), f((P + 15) // 16 * 16, 768), f(P, 24), f(P, V, 3), f(P, V, 2), f(P, 127, 3), f(P, 127, 2), f(P, 3)]
+st = torch.cuda.current_stream(dev).cuda_stream
+lib.mhmr_lbs_forward.argtypes = [C.c_void_p] * 8 + [C.c_int] + [C.c_void_p] * 9
+run = lambda: lib.mhmr_lbs_forward(C.byref(cs), pose.data_ptr(), shape.data_ptr(), expr.data_ptr(), loc.data_ptr(), dist.data_ptr(),
+                                   K.data_ptr(), det_b.data_ptr(), P, *[b.data_ptr() for b in bufs], st)
+nwg = lb["Vp"] // 48
+stamps = torch.zeros(nwg, 16, dtype=torch.int64, device=dev)
+for _ in range(5):
+    assert run() == 0
+torch.cuda.synchronize()
+lib.mhmr_debug_lbs_stamps.argtypes = [C.c_void_p]
+assert lib.mhmr_debug_lbs_stamps(stamps.data_ptr()) == 0
+assert run() == 0
+torch.cuda.synchronize()
+t = stamps.cpu().numpy().astype(np.float64)
+t0 = t[:, 0].min()
+names = ["start"] + [f"e{e} landed" for e in range(8)] + ["blend done", "skin folded", "stored"]
+print(f"P={P}: {nwg} workgroups; s_memtime ticks")
+print(f"{'stamp':14s} {'min':>8s} {'p10':>8s} {'median':>8s} {'p90':>8s} {'max':>8s}   (since the first workgroup's start)")
+for i, n in enumerate(names):
+    if (t[:, i] == 0).all():
+        continue
+    c = t[:, i] - t0
+    print(f"{n:14s} {c.min():8.0f} {np.percentile(c, 10):8.0f} {np.median(c):8.0f} {np.percentile(c, 90):8.0f} {c.max():8.0f}")
+print("per-workgroup phase lengths (median / p90):")
+for a, b in [(i, i + 1) for i in range(11)] + [(0, 11)]:
+    if (t[:, b] == 0).all() or (t[:, a] == 0).all():
+        continue
+    d = t[:, b] - t[:, a]
+    print(f"  {names[a]:12s} -> {names[b]:12s} {np.median(d):8.0f} {np.percentile(d, 90):8.0f}")
