@@ -66,17 +66,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     const int srow = tid >> 3;                                  // 0..63
     const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
     const int nt = g.K / 64;
-    // operand positions are 32-bit ELEMENT offsets from the uniform bases Pm / Qm (eligibility: M*K, N*K < 2^31): half the
-    // registers of per-lane 64-bit pointers
-    auto tile_src = [&](int tix, uint32_t& ps, uint32_t& qs, int& p0, int& q0) {
+    // an operand position = a wave-uniform 64-bit TILE base (scalar registers; any M x K) + a 32-bit element offset inside the tile
+    // (< 256 rows: fits for every ld below 2^22): half the vector registers of per-lane 64-bit pointers
+    const uint32_t p_lane = (uint32_t)srow * (uint32_t)ldp + (uint32_t)(schunk * 8);
+    const uint32_t q_lane = (uint32_t)srow * (uint32_t)ldq + (uint32_t)(schunk * 8);
+    auto tile_src = [&](int tix, const T*& pb, const T*& qb, int& p0, int& q0) {
         const int tn = tix % nbn, tm = tix / nbn;
         p0 = ROWMAJOR ? tn * 256 : tm * 256;
         q0 = ROWMAJOR ? tm * 256 : tn * 256;
-        ps = (uint32_t)(p0 + srow) * (uint32_t)ldp + (uint32_t)(schunk * 8);
-        qs = (uint32_t)(q0 + srow) * (uint32_t)ldq + (uint32_t)(schunk * 8);
+        pb = Pm + (size_t)p0 * (size_t)ldp;
+        qb = Qm + (size_t)q0 * (size_t)ldq;
     };
-    auto dma = [&](const T* base, uint32_t src, int ld, int half, int kt, int lds_off) {
-        const uint32_t o = src + (uint32_t)(128 * half) * (uint32_t)ld + (uint32_t)(kt * 64);
+    auto dma = [&](const T* base, uint32_t lane_off, int ld, int half, int kt, int lds_off) {
+        const uint32_t o = lane_off + (uint32_t)(128 * half) * (uint32_t)ld + (uint32_t)(kt * 64);
         char* d = smem + lds_off + w * 1024;
         glds16(base + o, d);
         glds16(base + (o + 64u * (uint32_t)ld), d + 8192);
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         }
     };
 
-    uint32_t p_src, q_src, p_nxt, q_nxt;
+    const T *p_src, *q_src, *p_nxt, *q_nxt;
     int p0, q0, p0n, q0n;
     if (first >= ntiles) return;             // (never with the launcher's grid; keeps barrier counts trivially equal)
     if (g.stagger_ticks > 0) {       // CU quarters start 0/1/2/3 x stagger_ticks late so their epilogue bursts interleave (gemm.hip)
@@ -145,13 +147,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
 
     // ---- prologue (first tile only): K tile 0 -> even buffer (all four halves), K tile 1 -> odd buffer (Q1, P0, Q0; P1 follows
     //      in phase 1 like in every later pair) ----
-    dma(Qm, q_src, ldq, 0, 0, SLOT_Q0);
-    dma(Pm, p_src, ldp, 0, 0, SLOT_P0);
-    dma(Qm, q_src, ldq, 1, 0, SLOT_Q1);
-    dma(Pm, p_src, ldp, 1, 0, SLOT_P1);
-    dma(Qm, q_src, ldq, 1, 1, BUF + SLOT_Q1);
-    dma(Pm, p_src, ldp, 0, 1, BUF + SLOT_P0);
-    dma(Qm, q_src, ldq, 0, 1, BUF + SLOT_Q0);
+    dma(q_src, q_lane, ldq, 0, 0, SLOT_Q0);
+    dma(p_src, p_lane, ldp, 0, 0, SLOT_P0);
+    dma(q_src, q_lane, ldq, 1, 0, SLOT_Q1);
+    dma(p_src, p_lane, ldp, 1, 0, SLOT_P1);
+    dma(q_src, q_lane, ldq, 1, 1, BUF + SLOT_Q1);
+    dma(p_src, p_lane, ldp, 0, 1, BUF + SLOT_P0);
+    dma(q_src, q_lane, ldq, 0, 1, BUF + SLOT_Q0);
 #pragma unroll
     for (int a = 0; a < 8; ++a) acc_init(a >> 2, (a >> 1) & 1, a & 1, p0, q0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -167,41 +169,41 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         for (int t = 0; t < nt; t += 2) {
             // K-tile indices past the end of this tile are the first K tiles of the next one
             const bool wrap = t + 2 >= nt;
-            const uint32_t p2 = wrap ? p_nxt : p_src;
-            const uint32_t q2 = wrap ? q_nxt : q_src;
+            const T* p2 = wrap ? p_nxt : p_src;
+            const T* q2 = wrap ? q_nxt : q_src;
             const int t1 = t + 1, t2 = wrap ? (has_next ? 0 : nt - 1) : t + 2, t3 = wrap ? (has_next ? 1 : nt - 1) : t + 3;
             // phase 1
             rdP(0, SLOT_P0);
-            dma(Pm, p_src, ldp, 1, t1, BUF + SLOT_P1); MHMR_WAIT_DMA();
+            dma(p_src, p_lane, ldp, 1, t1, BUF + SLOT_P1); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[0][0], QA); MHMR_SYNC();
             // phase 2
             rdQ(QB, 0, SLOT_Q1);
-            dma(Qm, q2, ldq, 0, t2, SLOT_Q0); MHMR_WAIT_DMA();
+            dma(q2, q_lane, ldq, 0, t2, SLOT_Q0); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[0][1], QB); MHMR_SYNC();
             // phase 3
             rdP(0, SLOT_P1);
-            dma(Pm, p2, ldp, 0, t2, SLOT_P0); MHMR_WAIT_DMA();
+            dma(p2, p_lane, ldp, 0, t2, SLOT_P0); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[1][1], QB); MHMR_SYNC();
             // phase 4
             rdQ(QB, 1, SLOT_Q1);
-            dma(Qm, q2, ldq, 1, t2, SLOT_Q1); MHMR_WAIT_DMA();
+            dma(q2, q_lane, ldq, 1, t2, SLOT_Q1); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[1][0], QA); MHMR_SYNC();
             // phase 5
             rdP(1, SLOT_P0);
-            dma(Pm, p2, ldp, 1, t2, SLOT_P1); MHMR_WAIT_DMA();
+            dma(p2, p_lane, ldp, 1, t2, SLOT_P1); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[0][1], QB); MHMR_SYNC();
             // phase 6
             rdQ(QA, 1, SLOT_Q0);
-            dma(Qm, q2, ldq, 1, t3, BUF + SLOT_Q1); MHMR_WAIT_DMA();
+            dma(q2, q_lane, ldq, 1, t3, BUF + SLOT_Q1); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[0][0], QA); MHMR_SYNC();
             // phase 7
             rdP(1, SLOT_P1);
-            dma(Pm, p2, ldp, 0, t3, BUF + SLOT_P0); MHMR_WAIT_DMA();
+            dma(p2, p_lane, ldp, 0, t3, BUF + SLOT_P0); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[1][0], QA); MHMR_SYNC();
             // phase 8 (the next pair's Q0; at the end of a tile it is read after the epilogue instead, so that QA's registers are
             // free for the epilogue)
             if (!wrap) rdQ(QA, 0, SLOT_Q0);
-            dma(Qm, q2, ldq, 0, t3, BUF + SLOT_Q0); MHMR_WAIT_DMA();
+            dma(q2, q_lane, ldq, 0, t3, BUF + SLOT_Q0); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[1][1], QB); MHMR_SYNC();
         }
 
@@ -379,7 +381,7 @@ int launch256_dt(const GemmArgs& g, hipStream_t s) {
 
 bool mhmr_gemm256_eligible(const GemmArgs& g) {
     if (g.epi == EPI_RESID && (uint64_t)g.M * (uint64_t)g.ldo * 4u >= (1ull << 32)) return false;   // 32-bit residual offsets
-    if ((uint64_t)g.M * (uint64_t)g.lda >= (1ull << 31) || (uint64_t)g.N * (uint64_t)g.ldw >= (1ull << 31)) return false;   // 32-bit operand offsets
+    if (g.lda >= (1 << 22) || g.ldw >= (1 << 22)) return false;      // 32-bit operand offsets INSIDE a 256-row tile (tile bases are 64-bit)
     return g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && (g.epi != EPI_VT || g.Tp % 64 == 0);
 }
 

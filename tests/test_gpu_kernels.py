@@ -39,6 +39,29 @@ def maxrel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def test_gemm256_rows_beyond_2_31_elements(L):
+    """M x K = 2^31 + 2^18 operand elements: the 256x256 kernel addresses tiles through 64-bit bases (it used to hand such shapes to
+    the slower 128x128 kernel silently).  The last row tile, 4 GiB into A, against torch on the same rows."""
+    M, N, K = (1 << 21) + 256, 256, 1024
+    tdt, dt = torch.float16, _lib.DT_F16
+    A = torch.empty(M, K, dtype=tdt, device=dev())
+    g = torch.Generator(device=dev()).manual_seed(3)
+    A[:256].normal_(generator=g)
+    A[-256:].normal_(generator=g)
+    A[256:-256].zero_()
+    W = (torch.randn(N, K, generator=g, device=dev()) / math.sqrt(K)).to(tdt)
+    bias = torch.randn(N, generator=g, device=dev())
+    out = torch.full((M, N), 7.0, dtype=tdt, device=dev())
+    _lib.check(L.mhmr_gemm16(A.data_ptr(), K, W.data_ptr(), K, M, N, K, bias.data_ptr(), None, out.data_ptr(), N, None, 0, 128, 1, M,
+                             _lib.EPI_OP16, dt, stream()), "gemm")
+    for rows in (slice(0, 256), slice(M - 256, M)):
+        ref = A[rows].float() @ W.float().T + bias
+        assert maxrel(out[rows].float(), ref) < 2e-3
+    assert float((out[256:512].float() - bias).abs().max()) < 2e-3          # a zero row tile: bias only
+    del A, out
+    torch.cuda.empty_cache()
+
+
 def test_gelu_epilogue_max_abs_error(L):
     """The fc1 epilogue's GELU is the three-term Abramowitz-Stegun 7.1.25 erfc form (csrc/mhmr_common.h gelu_fast), not erff:
     swept over x = a_m + b_n in [-10, 10] (step ~ 4e-5) through the GEMM itself (A[:, 0] = a, W[:, 0] = 1, bias = b), the stored
