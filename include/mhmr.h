@@ -65,7 +65,8 @@ typedef struct {
 typedef struct {
     int dtype;              /* MHMR_DT_*                                                                  */
     int B, S, C, H, L;      /* images, image size (S % 14 == 0), embed dim (= 64 H), heads, depth         */
-    int G, N, T, Tp;        /* S/14, G*G, N+1, T rounded up to a multiple of 128                          */
+    int G, N, T, Tp;        /* S/14, G*G, N+1, rows per image: T rounded up to a multiple of 64 (128 when a linear
+                               of the encoder runs on the 128x128 kernel: B*Tp or C not a multiple of 256) */
     int Kp;                 /* 588 rounded up to a multiple of 64 (= 640)                                 */
     const void* patch_w;    /* op16 [C, Kp]      patch_embed.proj.weight flattened (c,py,px), zero padded */
     const float* patch_b;   /* [C]                                                                        */

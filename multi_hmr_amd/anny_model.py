@@ -161,8 +161,8 @@ class Multi_HMR(nn.Module):
         B = x.shape[0]
         ws = self._workspace(P, B)
         L, st = _lib.lib(), torch.cuda.current_stream(dev).cuda_stream
-        Cd, N, G, Tp, D, J, nb = P["C"], P["N"], P["G"], P["Tp"], P["D"], self.n_joints, self.num_betas
-        Mp = roundup(B * N, 128)
+        Cd, N, G, D, J, nb = P["C"], P["N"], P["G"], P["D"], self.n_joints, self.num_betas
+        Mp, Tp = roundup(B * N, 128), ws["Tp"]
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
 
         # ---- encoder (encoder.py:33-67): backbone, class token -> field of view -> K, patch-level detection scores ----

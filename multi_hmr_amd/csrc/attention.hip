@@ -1,5 +1,5 @@
 // Flash-style multi-head self-attention forward for the DINOv2 blocks, head_dim = 64, non-causal,
-// T = N + 1 tokens padded to Tp (multiple of 128); keys >= T are masked.
+// T = N + 1 tokens padded to Tp (multiple of 64 = the key tile; query rows past Tp in the last workgroup are skipped); keys >= T are masked.
 //
 // Input contract: the Q half of `qk` arrives PRE-SCALED by MHMR_ATTN_QSCALE = 0.125 * log2(e) (the QK projection's epilogue
 // multiplies in fp32 before the one rounding to 16 bits, MHMR_EPI_OP16_QK), so the scores leave the matrix pipe already in the
@@ -316,7 +316,7 @@ int mhmr_attention_flag_count_impl(int B, int Tp, int H) { return ((Tp + 127) / 
 // the exact rescale inside the loop next to the sum test needed all 128 registers and fell to one LDS read per MFMA: 850).
 int mhmr_launch_attention_ex(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit_log2,
                              int variant, int* flags, hipStream_t s) {
-    if (C != H * 64 || Tp % 128 || T > Tp || T <= 0 || limit_log2 < 0.f || limit_log2 > 15.f) return MHMR_ERR_BAD_SHAPE;
+    if (C != H * 64 || Tp % 64 || T > Tp || T <= 0 || limit_log2 < 0.f || limit_log2 > 15.f) return MHMR_ERR_BAD_SHAPE;
     if (variant == 0 && flags == nullptr) return MHMR_ERR_BAD_ARG;
     const float limit = exp2f(limit_log2);
     prof_begin(PROF_ATTN, s);

@@ -118,7 +118,7 @@ int mhmr_layernorm16(const float* in, const float* w, const float* b, void* out1
 
 int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void* ctx16, int ldctx, void* stream) {
     if (!d || !x || !feat32 || !ctx16) return MHMR_ERR_BAD_ARG;
-    if (d->S % 14 || d->G * 14 != d->S || d->N != d->G * d->G || d->T != d->N + 1 || d->Tp % 128 || d->Tp < d->T ||
+    if (d->S % 14 || d->G * 14 != d->S || d->N != d->G * d->G || d->T != d->N + 1 || d->Tp % 64 || d->Tp < d->T ||
         d->C != d->H * 64 || d->Kp % 64 || d->Kp < 588 || (d->C != 384 && d->C != 768 && d->C != 1024))
         return MHMR_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;

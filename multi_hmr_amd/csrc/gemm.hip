@@ -248,7 +248,8 @@ static const bool g_force_gemm128 = getenv("MHMR_GEMM128") != nullptr;
 int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % BM || g.N % BN || g.K % BK) return MHMR_ERR_BAD_SHAPE;
     if (g.lda % 8 || g.ldw % 8) return MHMR_ERR_BAD_SHAPE;
-    if (g.epi == EPI_VT && (g.Tp % BM || g.N % 64)) return MHMR_ERR_BAD_SHAPE;
+    if (g.epi == EPI_VT && (g.Tp % 64 || g.N % 64)) return MHMR_ERR_BAD_SHAPE;
+    if (g.epi == EPI_VT && g.Tp % BM && (g_force_gemm128 || !mhmr_gemm256_eligible(g))) return MHMR_ERR_BAD_SHAPE;   // (this kernel's row tile)
     if (g.epi == EPI_OP16_QK && g.N % 128) return MHMR_ERR_BAD_SHAPE;      // Q | K halves are whole 64-column blocks
     prof_begin(PROF_GEMM, s);
     int rc;

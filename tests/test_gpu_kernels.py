@@ -180,9 +180,9 @@ def test_gemm_patch_and_vt_layouts(L, name, dt, tdt, tol):
 
 
 # ------------------------------------------------------------------------------------------------------ attention
-def _attn_inputs(B, H, T, tdt, seed, qscale=1.0):
+def _attn_inputs(B, H, T, tdt, seed, qscale=1.0, pad=128):
     """q is handed over PRE-SCALED (include/mhmr.h: the Q half of qk holds q * MHMR_ATTN_QSCALE, scores are in the exp2 domain)."""
-    C, Tp = H * 64, packing.roundup(T, 128)
+    C, Tp = H * 64, packing.roundup(T, pad)
     g = torch.Generator(device="cpu").manual_seed(seed)
     q = (torch.randn(B, Tp, H, 64, generator=g) * _lib.ATTN_QSCALE * qscale).to(dev()).to(tdt)
     k = torch.randn(B, Tp, H, 64, generator=g).to(dev()).to(tdt)
@@ -214,9 +214,9 @@ def _attn_ref(q, k, v, T, rows=None):
 
 
 @pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
-@pytest.mark.parametrize("B,H,T", [(2, 3, 200), (1, 2, 256), (1, 1, 65), (2, 6, 257)])
-def test_attention(L, name, dt, tdt, tol, B, H, T):
-    q, k, v, C, Tp = _attn_inputs(B, H, T, tdt, T)
+@pytest.mark.parametrize("B,H,T,pad", [(2, 3, 200, 128), (1, 2, 256, 128), (1, 1, 65, 128), (2, 6, 257, 128), (2, 6, 257, 64), (3, 2, 130, 64)])
+def test_attention(L, name, dt, tdt, tol, B, H, T, pad):
+    q, k, v, C, Tp = _attn_inputs(B, H, T, tdt, T, pad=pad)          # pad = 64: rows per image not a multiple of the 128-query workgroup
     k[0, min(T - 1, 70), 0] *= 6.0          # a spiked key moves the row maximum late in the loop
     got = _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt)[:, :T].double()
     err = float((got - _attn_ref(q, k, v, T)).abs().max())
@@ -224,12 +224,13 @@ def test_attention(L, name, dt, tdt, tol, B, H, T):
     assert torch.isfinite(got).all()
 
 
+@pytest.mark.parametrize("pad", [128, 64])               # rows per image: 2432 / 4224 / 8576 or 2368 / 4160 / 8512 (vit.padded_tokens)
 @pytest.mark.parametrize("T", [2305, 4097, 8465])        # 672^2, 896^2, 1288^2: 37 / 65 / 133 key tiles, the last one masked
-def test_attention_full_length_against_fp64(L, T):
+def test_attention_full_length_against_fp64(L, T, pad):
     """BASELINE sequence lengths, f16 operands, against fp64 on sampled query rows (first / last rows, tile and workgroup
     boundaries, random rows); absolute error of an output that is an average of N(0,1) values."""
-    B, H = 1, 2
-    q, k, v, C, Tp = _attn_inputs(B, H, T, torch.float16, T)
+    B, H = 2, 2
+    q, k, v, C, Tp = _attn_inputs(B, H, T, torch.float16, T, pad=pad)
     got = _attn_run(L, q, k, v, B, H, T, C, Tp, _lib.DT_F16, torch.float16)
     g = torch.Generator(device="cpu").manual_seed(1)
     rows = torch.cat([torch.tensor([0, 1, 31, 32, 63, 64, 127, 128, T - 130, T - 129, T - 65, T - 64, T - 2, T - 1]),

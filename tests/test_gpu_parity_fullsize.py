@@ -69,3 +69,29 @@ def test_full_size_forward_matches_reference_golden(name, precision, smplx_data,
     assert finite
     parity.assert_within(errs, precision, name)
     assert e_bb < 2 * TOL[precision], e_bb            # not a north-star output; informational bound
+
+
+def test_four_image_batch_uses_64_row_padding_and_matches_golden(smplx_data, mean_params):
+    """B = 4 images of ViT-L 672^2: rows per image = 2368 (a multiple of 64, vit.padded_tokens) instead of 2432; every image of
+    the batch is the golden case's image, so every person block must match the golden vectors."""
+    from multi_hmr_amd import vit
+    name = "vitl_672_full"
+    cfg = make_golden.CASES[name]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    model = Model(backbone=cfg["backbone"], img_size=cfg["img_size"], smplx_data=smplx_data, mean_params=mean_params, precision="f16")
+    model.load_state_dict(make_golden.case_state_dict(cfg), strict=True)
+    model = model.to("cuda:0").eval()
+    x, K, idx = make_golden.case_inputs(cfg)
+    assert x.shape[0] == 1
+    B, P1 = 4, idx[0].shape[0]
+    xb, Kb = x.repeat(B, 1, 1, 1), K.repeat(B, 1, 1)
+    idxb = tuple(torch.cat([(i + b) if j == 0 else i for b in range(B)]) for j, i in enumerate(idx))
+    out = model(xb.cuda(), idx=tuple(i.cuda() for i in idxb), K=Kb.cuda(), is_training=True)
+    assert vit.padded_tokens(model._packed, B) == 2368 and vit.padded_tokens(model._packed, 1) == 2432
+    vs = cfg.get("vstride", 1)
+    for b in (0, B - 1):
+        got = {k: out[k][b * P1:(b + 1) * P1].cpu() for k in CHECKED}
+        for k in ("v3d", "v2d"):
+            got[k] = got[k][:, ::vs]
+        errs = {k: rel(got[k].numpy(), gold[k]) for k in CHECKED}
+        parity.assert_within(errs, "f16", f"{name} image {b} of {B}")
