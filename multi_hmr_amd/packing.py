@@ -84,6 +84,12 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
     Ds = (D * 1024.0).astype(np.float32)
     hi = Ds.astype(np.float16)
     lo = (Ds - hi.astype(np.float32)).astype(np.float16)
+    # dynamic range of the pair: |D| 2^10 must stay a NORMAL f16 below 65504, and hi + lo must reproduce the fp32 value to
+    # 2^-22 relative (+ the f16 subnormal step where lo underflows) -- a body model with a wildly different scale fails here, loudly
+    if not (np.isfinite(hi).all() and float(np.abs(Ds).max()) < 6.0e4):
+        raise ValueError("blend basis x 2^10 leaves the f16 range")
+    if not bool((np.abs(hi.astype(np.float64) + lo.astype(np.float64) - Ds) <= 2.0 ** -22 * np.abs(Ds) + 2.0 ** -25).all()):
+        raise ValueError("blend basis: the f16 hi + lo pair does not reproduce the fp32 value")
     # tile-major: the slice of one 48-vertex tile is ONE contiguous 288 KiB block [Kb/8][hi|lo][3][48][8] (the kernel DMAs it into
     # LDS an eighth at a time: whole DRAM pages instead of 768-byte pieces 168 KB apart)
     T = LBS_TILE
@@ -108,6 +114,8 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
     Wd[: W.shape[1], :V] = W.T.astype(np.float32)
     whi = Wd.astype(np.float16)
     wlo = (Wd - whi.astype(np.float32)).astype(np.float16)
+    if not bool((np.abs(whi.astype(np.float64) + wlo.astype(np.float64) - Wd) <= 2.0 ** -22 * np.abs(Wd) + 2.0 ** -25).all()):
+        raise ValueError("skinning weights: the f16 hi + lo pair does not reproduce the fp32 value")
     wlay = lambda a: a.reshape(8, 8, Vp // T, T).transpose(2, 0, 3, 1)                        # [Vp/48, 8, 48, 8]
     skin16 = np.ascontiguousarray(np.stack([wlay(whi), wlay(wlo)], axis=2))                   # [Vp/48, 8, 2, 48, 8]
 

@@ -107,3 +107,14 @@ def test_gelu_three_term_erfc_error_bound():
     g = np.maximum(x, 0) - 0.5 * ax * p * np.exp2(-(u * u))
     ref = 0.5 * x * (1 + erf(x / math.sqrt(2)))
     assert np.abs(g - ref).max() < 2.6e-5
+
+
+def test_pack_smplx_rejects_a_basis_outside_the_f16_pair_range(smplx_data):
+    """The blend basis travels as an f16 pair scaled by 2^10: a body model whose blend shapes are 100x larger would overflow
+    silently on the GPU; pack_smplx refuses it."""
+    import pytest
+    bad = dict(smplx_data)
+    bad["posedirs"] = np.asarray(smplx_data["posedirs"]) * 1e4
+    with pytest.raises(ValueError):
+        packing.pack_smplx(bad, 10, "cpu")
+    packing.pack_smplx(smplx_data, 10, "cpu")
