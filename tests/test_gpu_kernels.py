@@ -224,6 +224,26 @@ def test_attention(L, name, dt, tdt, tol, B, H, T, pad):
     assert torch.isfinite(got).all()
 
 
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("target", [10.0, 40.0])
+def test_attention_last_key_rank_one_update(L, name, dt, tdt, tol, target):
+    """T = 64 n + 1: the default kernel form folds the lone key of the last tile in as a rank-1 update.  A last key that dominates
+    a query's softmax (score +10 above the level: stays in range) or leaves the 16-bit range (+40: the workgroup is flagged and
+    recomputed by the textbook form) must both match fp64."""
+    B, H, T = 2, 2, 257
+    q, k, v, C, Tp = _attn_inputs(B, H, T, tdt, 11, qscale=3.0)
+    kk = k.float()
+    for (bb, row, hh) in [(0, 3, 0), (1, 200, 1), (1, 256, 0)]:
+        d = q.float()[bb, row, hh]
+        kk[bb, T - 1, hh] = d / d.norm() ** 2 * target
+    k = kk.to(tdt)
+    got = _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=15.0, variant=0)[:, :T].double()
+    flagged = int(_attn_run.last_flags.sum().item())
+    assert (flagged > 0) == (target > 15.0), flagged
+    err = float((got - _attn_ref(q, k, v, T)).abs().max())
+    assert err < (4e-3 if name == "f16" else 3e-2), err
+
+
 @pytest.mark.parametrize("pad", [128, 64])               # rows per image: 2432 / 4224 / 8576 or 2368 / 4160 / 8512 (vit.padded_tokens)
 @pytest.mark.parametrize("T", [2305, 4097, 8465])        # 672^2, 896^2, 1288^2: 37 / 65 / 133 key tiles, the last one masked
 def test_attention_full_length_against_fp64(L, T, pad):
