@@ -59,7 +59,8 @@ constexpr int KV_TILE_BYTES = KB * 64 * 2;  // 8 KiB
 constexpr float BAND = 8.f;                 // MODE 2: half-width of the band around the reference level (exp2 domain)
 
 // NW waves x 32 query rows per workgroup; RING K/V tile slots in LDS (tile j + RING - 1 is in flight while tile j is consumed).
-// flags: one int per workgroup (logical id).  MODE 3 sets flags[wg] = 1 when its result must be recomputed; MODE 1 with a
+// flags: four ints per workgroup (logical id), one per wave.  MODE 3 writes every one of them (1 = this workgroup's result must be
+// recomputed, else 0: no memset in front of the launch); MODE 1 with a
 // non-null flags pointer returns immediately unless flags[wg] != 0.
 template <int DT, int NW, int RING, int MODE>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
@@ -76,7 +77,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
 
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     if constexpr (MODE == 1) {
-        if (flags != nullptr && flags[bid] == 0) return;      // fallback launch: only the flagged workgroups are recomputed
+        if (flags != nullptr) {                               // fallback launch: only the flagged workgroups are recomputed
+            const int4 f = *(const int4*)(flags + 4 * bid);   // (one flag per wave of the MODE 3 workgroup, written unconditionally)
+            if ((f.x | f.y | f.z | f.w) == 0) return;
+        }
     }
     const int qt = bid % nqt, bh = bid / nqt;
     const int b = bh / H, h = bh - b * H;
@@ -306,7 +310,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (MODE == 3) {
-        if (__any(bad) && lane == 0) flags[bid] = 1;          // the MODE 1 launch behind this one recomputes the workgroup
+        static_assert(MODE != 3 || NW == 4, "four flags per workgroup");
+        const bool anybad = __any(bad);
+        if (lane == 0) flags[4 * bid + w] = anybad ? 1 : 0;   // every wave writes its flag (no memset in front of the launch); the
+                                                              // MODE 1 launch behind this one recomputes a workgroup with any flag set
     }
     // ---- normalise and store: lane (q, hi) holds O[q][32 ds + 8 rg + 4 hi + 0..3] ----
     const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -340,8 +347,8 @@ int launch_attn(const void* qk, const void* vt, void* out, int B, int T, int Tp,
 
 }  // namespace
 
-// Number of ints of `flags` workspace the default attention form needs for a problem (one per workgroup).
-int mhmr_attention_flag_count_impl(int B, int Tp, int H) { return ((Tp + 127) / 128) * H * B; }
+// Number of ints of `flags` workspace the default attention form needs for a problem (one per wave of its 128-query workgroups).
+int mhmr_attention_flag_count_impl(int B, int Tp, int H) { return 4 * ((Tp + 127) / 128) * H * B; }
 
 // limit_log2 (variant 0): a workgroup is recomputed by the textbook kernel when a lane's tile sum of exp2(s - level) exceeded
 // 2^limit_log2 (0 <= limit_log2 <= 15; 15 = the shipped value "would leave the 16-bit range", 0 = nearly every workgroup).
@@ -360,8 +367,6 @@ int mhmr_launch_attention_ex(const void* qk, const void* vt, void* out, int B, i
     prof_begin(PROF_ATTN, s);
     switch (variant) {
         case 0: {
-            hipError_t e = hipMemsetAsync(flags, 0, sizeof(int) * (size_t)mhmr_attention_flag_count_impl(B, Tp, H), s);
-            if (e != hipSuccess) return (int)e;
             launch_attn<4, 2, 3>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
             launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);      // returns at once where flags[wg] == 0
             break;
