@@ -2,7 +2,7 @@
 """Where the SMPL-X vertex kernel's time goes: per-workgroup s_memtime stamps of wave 0 from a debug build of lbs.hip
 (-DMHMR_LBS_STAMPS, linked into tools/dbg/libmhmr_stamps.so; the product library carries no stamps).
   stamp 0 start | 1..8 eighth e's basis slice landed (barrier passed) | 9 blend done | 10 skinning products folded | 11 stores issued
-usage: MHMR_LIB=tools/dbg/libmhmr_stamps.so python tools/lbs_timeline.py [P]"""
+usage: bash tools/build_lbs_stamps.sh; MHMR_LIB=tools/dbg/libmhmr_stamps.so python tools/lbs_timeline.py [P]"""
 import ctypes as C, os, sys
 import numpy as np
 import torch
