@@ -281,8 +281,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
             // dimensions of both), the dot product closes over the lane pair; p in fp32 (not rounded to 16 bits: this key is not an
             // MFMA operand); its V row goes through a wave-private 256-byte LDS strip so that a lane can pick the 32 output
             // dimensions its accumulators hold
-            const int kl = T - 1;
-            const Tt* kp = qk + (row0 + kl) * ldq + C + h * 64 + 8 * hi;
+            // (every address below is derived HERE from values made opaque to the optimiser: hoisted above the loop, the
+            // loop-invariant parts of these addresses were five more live registers -> 24 B of scratch per lane, 100 MB per call)
+            int kl = T - 1, lane2 = lane;
+            asm volatile("" : "+s"(kl), "+v"(lane2));
+            const int hi2 = lane2 >> 5;
+            const Tt* kp = qk + (row0 + kl) * ldq + C + h * 64 + 8 * hi2;
             float dot = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -296,13 +300,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
             if (hi == 0) l_run += p;                            // (the row sum is the sum over the lane pair)
             const int klp = (kl & ~12) | ((kl & 4) << 1) | ((kl & 8) >> 1);          // V^T columns are key-permuted (bits 2 <-> 3)
             float* vl = (float*)(smem + RING * 2 * KV_TILE_BYTES) + w * 64;
-            vl[lane] = (float)vt[((size_t)(b * H + h) * 64 + lane) * Tp + klp];
+            vl[lane2] = (float)vt[((size_t)(b * H + h) * 64 + lane2) * Tp + klp];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the strip is written and read by this wave only
 #pragma unroll
             for (int ds = 0; ds < 2; ++ds)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-                    const f32x4 v4 = *(const f32x4*)(vl + 32 * ds + 8 * rg + 4 * hi);
+                    const f32x4 v4 = *(const f32x4*)(vl + 32 * ds + 8 * rg + 4 * hi2);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[ds][4 * rg + e] = __builtin_fmaf(v4[e], p, o[ds][4 * rg + e]);
                 }
@@ -319,7 +323,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = active ? 1.0f / l_tot : 0.f;
     if (!in_buf) return;
-    Tt* op = (Tt*)out_ + (row0 + q_row) * C + h * 64 + 4 * hi;
+    int lane3 = lane;
+    asm volatile("" : "+v"(lane3));                               // (the store address is formed here, not carried through the loop)
+    Tt* op = (Tt*)out_ + (row0 + (qt * QB + 32 * w + (lane3 & 31))) * C + h * 64 + 4 * (lane3 >> 5);
 #pragma unroll
     for (int ds = 0; ds < 2; ++ds)
 #pragma unroll
