@@ -101,8 +101,10 @@ int mhmr_attention16(const void* qk, const void* vt, void* out, int B, int T, in
  * level from the scores inside the matrix pipe; they differ in how the level follows the row maximum:
  *   variant 0  (what mhmr_vit_forward runs) level = exact row maximum of key tile 0, no maximum afterwards; a workgroup in which
  *              a lane's tile sum of exp2(score - level) exceeded 2^limit_log2 (0 <= limit_log2 <= 15; 15 = "would leave the
- *              16-bit range", 0 = nearly every workgroup) sets its entry of `flags` and is recomputed by variant 1, launched
- *              right behind it on the same stream.  flags: int workspace of mhmr_attention_flag_count(B, Tp, H) entries.
+ *              16-bit range", 0 = nearly every workgroup) sets its entries of `flags` and is recomputed by variant 1, launched
+ *              right behind it on the same stream.  flags: int workspace of mhmr_attention_flag_count(B, Tp, H) entries (four
+ *              per 128-query workgroup); the call writes every entry, the caller need not clear them.  T = 64 n + 1: the lone
+ *              key of the last tile is folded in as a rank-1 update.
  *   variant 1  textbook online softmax (running maximum + subtract every tile).        flags unused (NULL)
  *   variant 2  level moves when the running maximum leaves a +-8 band (what mhmr_attention16 runs).   flags unused (NULL)
  *   variant 3  variant 2 with 8-wave workgroups.                                        flags unused (NULL)              */

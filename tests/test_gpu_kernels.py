@@ -198,7 +198,7 @@ def _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=None, variant=0):
     if thr is None:
         _lib.check(L.mhmr_attention16(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), B, T, Tp, C, H, dt, stream()), "attention")
     else:
-        flags = torch.full((L.mhmr_attention_flag_count(B, Tp, H),), 7, dtype=torch.int32, device=dev())   # (the call zeroes them)
+        flags = torch.full((L.mhmr_attention_flag_count(B, Tp, H),), 7, dtype=torch.int32, device=dev())   # (the call writes every entry)
         _lib.check(L.mhmr_attention16_ex(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), B, T, Tp, C, H, dt, thr, variant,
                                          flags.data_ptr() if variant == 0 else None, stream()), "attention_ex")
         _attn_run.last_flags = flags
