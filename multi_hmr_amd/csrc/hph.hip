@@ -62,6 +62,64 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
     }
 }
 
+// The same product with the k range split over the four waves of a workgroup (one 16 x 32 tile per workgroup, partial sums added
+// in wave order through LDS: deterministic).  At the HPH shapes (M = persons <= a few hundred, K = N = 1024) the form above runs
+// two waves per CU through 64 dependent load -> MFMA iterations (30 us per linear, 16 linears per forward); here each wave has
+// 16 iterations and a CU holds eight waves.
+__global__ __launch_bounds__(256) void linear_f32_splitk_kernel(const float* __restrict__ X, int ldx, const int* __restrict__ row_idx,
+                                                                const float* __restrict__ W, int ldw, const float* __restrict__ bias,
+                                                                const float* R, int ldr, float* Y, int ldy, int M, int N, int K,
+                                                                int act) {
+    __shared__ f32x4 part[3][2][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 32;
+    int mrow = min(m0 + l15, M - 1);
+    if (row_idx) mrow = row_idx[mrow];
+    const int nch = K >> 4, cb = nch >> 2, cr = nch & 3;          // 16-wide k chunks, split as evenly as they go
+    const int kq = 16 * (cb + (w < cr ? 1 : 0)), k0 = 16 * (w * cb + min(w, cr));
+    const float* xp = X + (size_t)mrow * ldx + 4 * g + k0;
+    const float* wp0 = W + (size_t)min(n0 + l15, N - 1) * ldw + 4 * g + k0;
+    const float* wp1 = W + (size_t)min(n0 + 16 + l15, N - 1) * ldw + 4 * g + k0;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = 0; k < kq; k += 16) {
+        const f32x4 xa = *(const f32x4*)(xp + k);
+        const f32x4 w0 = *(const f32x4*)(wp0 + k);
+        const f32x4 w1 = *(const f32x4*)(wp1 + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[e], w0[e], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[e], w1[e], acc1, 0, 0, 0);
+        }
+    }
+    if (w > 0) { part[w - 1][0][lane] = acc0; part[w - 1][1][lane] = acc1; }
+    __syncthreads();
+    if (w > 0) return;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const f32x4 p0 = part[q][0][lane], p1 = part[q][1][lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc0[r] += p0[r]; acc1[r] += p1[r]; }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = n0 + 16 * t + l15;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 4 * g + r;
+            if (m >= M) continue;
+            float v = (t == 0 ? acc0[r] : acc1[r]) + bv;
+            if (act == MHMR_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (act == MHMR_ACT_GELU) v = gelu_erf(v);
+            if (R) v += R[(size_t)m * ldr + n];
+            Y[(size_t)m * ldy + n] = v;
+        }
+    }
+}
+
 // One wave per row, fp32 in / fp32 out, C % 64 == 0, C <= 2048.
 __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restrict__ in, const float* __restrict__ gw,
                                                             const float* __restrict__ gb, float* __restrict__ out, int rows,
@@ -464,8 +522,12 @@ __global__ void loc_kernel(const float* __restrict__ offset, const int* __restri
 int mhmr_launch_linear_f32(const float* X, int ldx, const int* row_idx, const float* W, int ldw, const float* bias,
                            const float* R, int ldr, float* Y, int ldy, int M, int N, int K, int act, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0 || K % 16 || ldx % 4 || ldw % 4) return MHMR_ERR_BAD_SHAPE;
-    hipLaunchKernelGGL(linear_f32_kernel, dim3((N + 127) / 128, (M + 15) / 16), dim3(256), 0, s, X, ldx, row_idx, W, ldw,
-                       bias, R, ldr, Y, ldy, M, N, K, act);
+    if (K >= 256 && (long long)((N + 127) / 128) * ((M + 15) / 16) < 1024)       // few tiles, long k: split k over the waves
+        hipLaunchKernelGGL(linear_f32_splitk_kernel, dim3((N + 31) / 32, (M + 15) / 16), dim3(256), 0, s, X, ldx, row_idx, W, ldw,
+                           bias, R, ldr, Y, ldy, M, N, K, act);
+    else
+        hipLaunchKernelGGL(linear_f32_kernel, dim3((N + 127) / 128, (M + 15) / 16), dim3(256), 0, s, X, ldx, row_idx, W, ldw,
+                           bias, R, ldr, Y, ldy, M, N, K, act);
     MHMR_CHECK_LAUNCH();
     return 0;
 }

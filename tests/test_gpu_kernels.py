@@ -310,7 +310,8 @@ def test_layernorm16(L, name, dt, tdt, tol, C):
 
 def test_linear_f32_and_layernorm_f32(L):
     g = torch.Generator(device="cpu").manual_seed(3)
-    for (M, N, K, act) in [(37, 130, 48, 0), (5, 2, 384, 1), (64, 1024, 1456, 2), (257, 341, 1024, 0)]:
+    # (K % 64 == 0, K >= 256 and few tiles: the split-k form; otherwise one wave per 16 x 32 tile over the whole k range)
+    for (M, N, K, act) in [(37, 130, 48, 0), (5, 2, 384, 1), (64, 1024, 1456, 2), (257, 341, 1024, 0), (256, 1024, 1024, 2), (300, 159, 2048, 1)]:
         X = torch.randn(M, K, generator=g).to(dev())
         W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev())
         b = torch.randn(N, generator=g).to(dev())
@@ -327,6 +328,11 @@ def test_linear_f32_and_layernorm_f32(L):
     ridx = torch.tensor([3, 3, 49, 0, 17], dtype=torch.int32, device=dev())
     Y = torch.zeros(5, 20, device=dev())
     _lib.check(L.mhmr_linear_f32(X.data_ptr(), 64, ridx.data_ptr(), W.data_ptr(), 64, None, None, 0, Y.data_ptr(), 20, 5, 20, 64, 0, stream()), "linear")
+    assert maxrel(Y, X[ridx.long()].double() @ W.double().T) < 1e-5
+    X = torch.randn(50, 256, device=dev())
+    W = torch.randn(20, 256, device=dev()) / 16
+    Y = torch.zeros(5, 20, device=dev())
+    _lib.check(L.mhmr_linear_f32(X.data_ptr(), 256, ridx.data_ptr(), W.data_ptr(), 256, None, None, 0, Y.data_ptr(), 20, 5, 20, 256, 0, stream()), "linear")
     assert maxrel(Y, X[ridx.long()].double() @ W.double().T) < 1e-5
     x = torch.randn(33, 1024, device=dev()) * 2 - 0.5
     w, b = torch.randn(1024, device=dev()), torch.randn(1024, device=dev())
