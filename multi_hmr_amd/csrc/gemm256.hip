@@ -138,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
 
     const T *p_src, *q_src, *p_nxt, *q_nxt;
     int p0, q0, p0n, q0n;
-    if (first >= ntiles) return;             // (never with the launcher's grid; keeps barrier counts trivially equal)
+    if (first >= ntiles) return;             // (never with the launcher's grid: G <= ntiles; keeps barrier counts trivially equal)
     if (g.stagger_ticks > 0) {       // CU quarters start 0/1/2/3 x stagger_ticks late so their epilogue bursts interleave (gemm.hip)
         const uint64_t t0 = wall_clock64(), dl = (uint64_t)g.stagger_ticks * (uint64_t)(first * 4 / G);
         while (wall_clock64() - t0 < dl) __builtin_amdgcn_s_sleep(32);
@@ -159,12 +159,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MHMR_SYNC();
 
-    for (int tix = first; tix < ntiles; tix += G) {
+    // this workgroup's tiles: one per full round at `first`, and the tiles of the last, partial round go to the LOWEST block
+    // indices (b < ntiles % G): when another persistent launch is draining beside this one, the workgroups dispatched first are
+    // then the ones with the extra tile
+    const int full = ntiles / G, nmine = full + (b < ntiles - full * G ? 1 : 0);
+    auto tile_of = [&](int r) { return r < full ? first + r * G : full * G + b; };
+    for (int r = 0; r < nmine; ++r) {
+        const int tix = tile_of(r);
         // Q0 of this tile's first K tile (landed and published by the previous pair's phase-8 wait + barrier, or by the prologue)
         rdQ(QA, 0, SLOT_Q0);
         if (wp == 1) { MHMR_SYNC(); }       // stagger: during the K loop group 1 runs one barrier behind group 0
-        const bool has_next = tix + G < ntiles;
-        if (has_next) tile_src(tix + G, p_nxt, q_nxt, p0n, q0n);
+        const bool has_next = r + 1 < nmine;
+        if (has_next) tile_src(tile_of(r + 1), p_nxt, q_nxt, p0n, q0n);
         else { p_nxt = p_src; q_nxt = q_src; p0n = p0; q0n = q0; }     // last tile: harmless re-load into slots nobody reads
         for (int t = 0; t < nt; t += 2) {
             // K-tile indices past the end of this tile are the first K tiles of the next one
