@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define MHMR_VERSION 100
+#define MHMR_VERSION 101   /* 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
 
 #define MHMR_OK 0
 #define MHMR_ERR_BAD_ARG (-1)
@@ -60,13 +60,19 @@ typedef struct {
     const float* fc1_b;           /* [4C]                                                            */
     const void* fc2_w;            /* op16 [C, 4C]                         blocks.i.mlp.fc2          */
     const float *fc2_b, *ls2;     /* [C], [C] (ls2.gamma)                                           */
+    /* Optional low halves of the two projections whose one-time weight rounding dominates the 1e-3 parity budget:
+     * op16 [C, 2C] = [W_hi | W_lo] along k with W_hi = op16(W), W_lo = op16(W - W_hi); NULL = single pass over qkv_w[2C:3C] / proj_w. */
+    const void* v_w2;             /* blocks.i.attn.qkv.weight[2C:3C] as hi | lo, or NULL              */
+    const void* proj_w2;          /* blocks.i.attn.proj.weight as hi | lo, or NULL                    */
 } mhmr_vit_block;
 
 typedef struct {
     int dtype;              /* MHMR_DT_*                                                                  */
     int B, S, C, H, L;      /* images, image size (S % 14 == 0), embed dim (= 64 H), heads, depth         */
     int G, N, T, Tp;        /* S/14, G*G, N+1, rows per image: T rounded up to a multiple of 64 (128 when a linear
-                               of the encoder runs on the 128x128 kernel: B*Tp or C not a multiple of 256) */
+                               of the encoder runs on the 128x128 kernel: B*Tp or C not a multiple of 256).
+                               Token rows of image b: patch n (= y*G + x) at row b*Tp + n, the CLASS token at row b*Tp + N
+                               (last: attention is permutation-equivariant), zeros behind it */
     int Kp;                 /* 588 rounded up to a multiple of 64 (= 640)                                 */
     const void* patch_w;    /* op16 [C, Kp]      patch_embed.proj.weight flattened (c,py,px), zero padded */
     const float* patch_b;   /* [C]                                                                        */
@@ -93,6 +99,18 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
 int mhmr_gemm16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias,
                 const float* gamma, void* out, int ldo, const float* pos, int Np, int Tp, int H, int Mvalid, int epi,
                 int dtype, void* stream);
+/* The same with (a) a token-row map: logical activation / output row m = b * img_rows + n lives at physical row b * img_stride + n
+ * (img_rows % 256 == 0; 0 = rows are physical), so a GEMM can cover the patch rows of every image and skip its class / padding rows;
+ * (b) a low-half weight pass: W = [W_hi | W_lo] along k, K = 2 * a_k, the activation's k index wraps at a_k (0 = off).            */
+int mhmr_gemm16_ex(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias,
+                   const float* gamma, void* out, int ldo, const float* pos, int Np, int Tp, int H, int Mvalid, int epi,
+                   int dtype, int img_rows, int img_stride, int a_k, void* stream);
+/* The class-token rows of a block linear (csrc/vit_cls.hip): B rows, a_stride / o_stride elements apart.  epi 0: Q | K | V projection
+ * (columns n_base + [0, N) of [Q * MHMR_ATTN_QSCALE | K | V]; Q, K -> out16 row, V -> column vcol of vt [B,H,64,Tp]); epi 1: out32 +=
+ * gamma * (acc + bias); epi 2: out16 = gelu(acc + bias).  N % 16 == 0, K % 128 == 0, a_k as in mhmr_gemm16_ex.                     */
+int mhmr_cls_linear16(const void* A, long long a_stride, const void* W, int ldw, int B, int N, int K, int a_k, const float* bias,
+                      const float* gamma, void* out, long long o_stride, int n_base, int C, void* vt, int H, int Tp, int vcol,
+                      int epi, int dtype, void* stream);
 /* qk: op16 [B*Tp, 2C] = (Q * MHMR_ATTN_QSCALE | K), head h at columns h*64; vt: op16 [B,H,64,Tp] key-permuted V^T
  * (MHMR_EPI_VT); out: op16 [B*Tp, C] = softmax_2(Q K^T) V over the T real keys of each image.                    */
 int mhmr_attention16(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype,
@@ -107,7 +125,9 @@ int mhmr_attention16(const void* qk, const void* vt, void* out, int B, int T, in
  *              key of the last tile is folded in as a rank-1 update.
  *   variant 1  textbook online softmax (running maximum + subtract every tile).        flags unused (NULL)
  *   variant 2  level moves when the running maximum leaves a +-8 band (what mhmr_attention16 runs).   flags unused (NULL)
- *   variant 3  variant 2 with 8-wave workgroups.                                        flags unused (NULL)              */
+ *   variant 3  variant 2 with 8-wave workgroups.                                        flags unused (NULL)
+ *   variant 4 / 5  the arithmetic of variant 0 with 64 queries per wave (two 32-query blocks: a wave's softmax of one block issues in
+ *              the shadow of its MFMAs on the other; 256-query workgroups, 3- / 2-slot K/V ring); flags as for variant 0.            */
 int mhmr_attention16_ex(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype,
                         float limit_log2, int variant, int* flags, void* stream);
 int mhmr_attention_flag_count(int B, int Tp, int H);

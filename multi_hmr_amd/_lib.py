@@ -12,9 +12,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmhmr.so")
-SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "vit_misc.hip", "hph.hip", "lbs.hip", "preprocess.hip", "evalm.hip", "anny.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "vit_misc.hip", "vit_cls.hip", "hph.hip", "lbs.hip", "preprocess.hip", "evalm.hip", "anny.hip", "capi.hip"]
 HEADERS = ["mhmr_common.h", "mhmr_internal.h", os.path.join("..", "..", "include", "mhmr.h")]
 
+VERSION = 101                       # include/mhmr.h MHMR_VERSION (struct layouts and entry-point semantics)
 DT_BF16, DT_F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 EPI_OP16, EPI_OP16_GELU, EPI_OP16_RELU, EPI_RESID, EPI_PATCH, EPI_F32, EPI_VT, EPI_OP16_QK = range(8)
@@ -70,7 +71,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 class VitBlock(C.Structure):
     _fields_ = [(n, _vp) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1", "ln2_w", "ln2_b",
-                                   "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+                                   "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "v_w2", "proj_w2")]
 
 
 class VitDesc(C.Structure):
@@ -102,6 +103,8 @@ _SIGS = {
     "mhmr_version": ([], _i),
     "mhmr_vit_forward": ([C.POINTER(VitDesc), _vp, _vp, _vp, _i, _vp], _i),
     "mhmr_gemm16": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "mhmr_gemm16_ex": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "mhmr_cls_linear16": ([_vp, C.c_longlong, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, C.c_longlong, _i, _i, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "mhmr_attention16": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mhmr_attention16_ex": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp], _i),
     "mhmr_attention_flag_count": ([_i, _i, _i], _i),
@@ -142,6 +145,8 @@ def lib() -> C.CDLL:
         for name, (args, res) in _SIGS.items():
             fn = getattr(l, name)          # AttributeError if the symbol is not exported
             fn.argtypes, fn.restype = args, res
+        if l.mhmr_version() != VERSION:
+            raise MhmrError(f"{LIB_PATH} is version {l.mhmr_version()}, this package binds version {VERSION} (include/mhmr.h): rebuild")
         _lib = l
     return _lib
 

@@ -118,7 +118,7 @@ class Multi_HMR(nn.Module):
                  det2_b=f32(e.mlp_det[2].bias), fov0_w=f32(e.mlp_fov_unique[0].weight), fov0_b=f32(e.mlp_fov_unique[0].bias),
                  fov2_w=f32(e.mlp_fov_unique[2].weight), fov2_b=f32(e.mlp_fov_unique[2].bias), norm_w=f32(enc.norm.weight),
                  norm_b=f32(enc.norm.bias), tok_w=op(self.dec_to_token.weight), tok_b=f32(self.dec_to_token.bias),
-                 # the patch-scatter epilogue adds pos[1 + n]: row 0 is the (unused) class-token slot
+                 # the patch-scatter epilogue adds pos[1 + n]: pos row 0 is the (unused) class-token entry
                  dec_pos=torch.cat([torch.zeros(1, D, device=device), f32(self.dec_pos_emb)], 0).contiguous(),
                  useful=f32(self.useful_rotmat.reshape(-1)), init_pose=f32(self.init_body_pose.reshape(-1)))
         Kpose = roundup(D + 6 * J, 16)
@@ -168,7 +168,7 @@ class Multi_HMR(nn.Module):
         # ---- encoder (encoder.py:33-67): backbone, class token -> field of view -> K, patch-level detection scores ----
         _lib.check(L.mhmr_vit_forward(C.byref(ws["vit_desc"]), x.data_ptr(), ws["feat32"].data_ptr(), ws["ctx16"].data_ptr(), P["Kc"], st),
                    "mhmr_vit_forward")
-        cls_rows = ws["resid"].view(B, Tp, Cd)[:, 0].contiguous()                      # un-normed class tokens (a [B, C] copy)
+        cls_rows = ws["resid"].view(B, Tp, Cd)[:, N].contiguous()                      # un-normed class tokens (a [B, C] copy; the class token is the LAST token row of an image)
         cls = f(B, Cd)
         _lib.check(L.mhmr_layernorm_f32(cls_rows.data_ptr(), P["norm_w"].data_ptr(), P["norm_b"].data_ptr(), cls.data_ptr(), B, Cd, 1e-6, st),
                    "mhmr_layernorm_f32")
@@ -210,7 +210,7 @@ class Multi_HMR(nn.Module):
         _lib.check(L.mhmr_gemm16(ws["ctx16"].data_ptr(), P["Kc"], P["tok_w"].data_ptr(), Cd, Mp, D, Cd, P["tok_b"].data_ptr(), None,
                                  dec_emb.data_ptr(), D, P["dec_pos"].data_ptr(), N, N, 1, B * N, _lib.EPI_PATCH, P["dt_id"], st),
                    "dec_to_token")
-        tokens = dec_emb[1: 1 + B * N].view(B, N, D)        # the epilogue writes row (m / N) * N + 1 + m % N: shifted by the class slot
+        tokens = dec_emb[: B * N].view(B, N, D)             # the epilogue writes row (m / N) * Tp + m % N with Tp = N here
 
         # ---- queries / context (130-138) and the decoder (141-142) ----
         values, counts = torch.unique(idx[0], sorted=True, return_counts=True)

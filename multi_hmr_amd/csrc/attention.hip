@@ -43,6 +43,7 @@
 // k-step ahead with pinned issue order (120 VGPRs) 933-936 vs 900-953 TFLOP/s f16 for this form, 990-997 vs 945-1016 bf16; 8 waves
 // with a 3-slot ring 862-908; both together 954 / 1006: all inside the run-to-run spread of the plain 4-wave form, which stays.
 #include <stdlib.h>
+#include <type_traits>
 #include "mhmr_common.h"
 #include "mhmr_internal.h"
 
@@ -55,6 +56,9 @@ __device__ __forceinline__ float max_lane32(float v) {
 }
 
 constexpr int KB = 64;
+#ifndef MHMR_ATTN_DEFAULT_VARIANT
+#define MHMR_ATTN_DEFAULT_VARIANT 0          // what mhmr_vit_forward runs (MHMR_ATTN_VARIANT overrides at run time: A/B measurements)
+#endif
 constexpr int KV_TILE_BYTES = KB * 64 * 2;  // 8 KiB
 constexpr float BAND = 8.f;                 // MODE 2: half-width of the band around the reference level (exp2 domain)
 
@@ -337,6 +341,318 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// 64 queries per wave (round 3).  The 32-query form above runs four waves per SIMD, each with ONE score block: a wave's softmax can
+// only start when its own score MFMAs have finished, so inside a wave the matrix pipe and the VALU strictly alternate, and the pipe is
+// busy only when ANOTHER wave of the SIMD happens to be in a matrix section (measured 53 % busy with 51 % of the wave cycles "ready but
+// stalled").  Here a wave owns TWO 32-query blocks A and B (256 registers, two waves per SIMD, 256 queries per workgroup) and its own
+// instruction stream overlaps the two pipes:
+//     QK_A | QK_B + softmax_A | PV_A + softmax_B | PV_B            (matrix | matrix + VALU | matrix + VALU | matrix)
+// Per key tile a workgroup still stages 16 KiB once -- for twice the queries, so the LDS-DMA / L2 traffic per flop halves.
+// Same arithmetic as MODE 3 above (reference level = exact row maximum of key tile 0, then fixed; flagged workgroups are recomputed by
+// the textbook MODE 1 kernel; the lone last key of T = 64 n + 1 as a rank-1 update).  flags are written in the 128-query MODE 1
+// workgroup numbering (four per workgroup, one per 32-query block).
+template <int DT>
+struct QBlock {
+    typename Op<DT>::V8 qf[4];
+    f32x16 o[2];
+    float mneg;         // -m_ref; splatted into the first C operand of the score MFMAs at the top of every QK section (16 v_mov per block
+                        // and tile; a resident 16-register tuple per block does not fit beside two score blocks in 256 registers)
+    float l_run;
+    bool bad;
+};
+
+template <int DT, int RING>
+__global__ __launch_bounds__(256, 2) void attn64_kernel(const void* __restrict__ qk_, const void* __restrict__ vt_, void* __restrict__ out_,
+                                                        int T, int Tp, int C, int H, int nqt, float limit, int* __restrict__ flags) {
+    typedef typename Op<DT>::T Tt;
+    typedef typename Op<DT>::V8 V8;
+    typedef typename Op<DT>::V4 V4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [RING][K tile | Vt tile] + 4 x 256 B strips
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = bid % nqt, bh = bid / nqt;
+    const int b = bh / H, h = bh - b * H;
+
+    const Tt* qk = (const Tt*)qk_;
+    const Tt* vt = (const Tt*)vt_;
+    const int ldq = 2 * C;
+    const size_t row0 = (size_t)b * Tp;
+    const int qr0 = qt * 256 + 64 * w;          // first query row of the wave
+    const bool active = qr0 < T;                // (wave-uniform) a wave without a real query row only stages and meets the barriers
+    QBlock<DT> A, Bq;
+    auto init_block = [&](QBlock<DT>& x, int first_row) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) x.qf[ks] = V8{};
+        if (first_row < Tp) {                   // rows past the padded rows of the image are not read (and not stored)
+            const Tt* qp = qk + (row0 + first_row + l31) * ldq + h * 64 + 8 * hi;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) x.qf[ks] = *(const V8*)(qp + 16 * ks);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x.o[i][r] = 0.f;
+        x.mneg = 0.f;
+        x.l_run = 0.f;
+        x.bad = false;
+    };
+    init_block(A, qr0);
+    init_block(Bq, qr0 + 32);
+
+    const int srow = tid >> 3;
+    const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
+    const Tt* k_src = qk + (row0 + srow) * ldq + C + h * 64 + schunk * 8;
+    const Tt* v_src = vt + ((size_t)(b * H + h) * 64 + srow) * Tp + schunk * 8;
+    auto stage = [&](int j, int buf) {
+        char* sk = smem + buf * (2 * KV_TILE_BYTES) + w * 1024;
+        char* sv = sk + KV_TILE_BYTES;
+        const Tt* kp = k_src + (size_t)j * KB * ldq;
+        const Tt* vp = v_src + j * KB;
+        glds16(kp, sk);
+        glds16(kp + (size_t)32 * ldq, sk + 4096);
+        glds16(vp, sv);
+        glds16(vp + (size_t)32 * Tp, sv + 4096);
+    };
+    const int fsw = (lane >> 1) & 7;
+    const bool tail1 = (T & (KB - 1)) == 1 && T > KB;
+    const int ntile = tail1 ? T / KB : (T + KB - 1) / KB;
+    const int nfull = tail1 ? ntile : T / KB;                      // tiles without masked keys
+
+    // ---- building blocks of one key tile ----
+    auto splat = [&](float m) {                 // (opaque per tile: hoisted out of the tile loop it would be a resident tuple again)
+        asm volatile("" : "+v"(m));
+        f32x16 t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = m;
+        return t;
+    };
+    auto mask_block = [&](f32x16 (&s)[2], int j) {                 // keys >= T of the last, partial tile
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (j * KB + 32 * sub + crow(r, hi) >= T) s[sub][r] = -INFINITY;
+    };
+    auto level_block = [&](QBlock<DT>& x, f32x16 (&s)[2]) {        // tile 0: the level becomes the exact row maximum
+        float mt = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[1][r]);
+        mt = max_lane32(mt);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[sub][r] -= mt;
+        x.mneg = -mt;
+    };
+#pragma unroll
+    for (int t = 0; t < RING - 1; ++t) stage(t < ntile ? t : ntile - 1, t);
+    int buf = 0, nbuf = RING - 1;
+    // ring bookkeeping of one key tile: landing wait + barrier, slot pointers, and the next DMA (issued by the caller where it suits)
+    auto tile_begin = [&](const char*& sk, const char*& sv, int& nbuf_now) {
+        if constexpr (RING == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if constexpr (RING == 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        static_assert(RING >= 2 && RING <= 4, "counted waits");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        sk = smem + buf * (2 * KV_TILE_BYTES);
+        sv = sk + KV_TILE_BYTES;
+        nbuf_now = nbuf;
+        buf = buf == RING - 1 ? 0 : buf + 1;
+        nbuf = nbuf == RING - 1 ? 0 : nbuf + 1;
+    };
+    // one key tile, hand-pipelined (FIRST: tile 0 sets the reference level; MASKED: a last tile with keys >= T): four sections of four steps; a step = the NEXT step's two operand fragments requested from
+    // LDS (double-buffered: 16 registers), two MFMAs on the fragments requested one step earlier, and -- in the two middle sections --
+    // a quarter of the other block's softmax (8 exp, 8 adds, 4 converts) in the shadow of those MFMAs.  A scheduling barrier closes
+    // every step: the register footprint is what is written here (hipcc's own schedule of the same work requested all eight K
+    // fragments up front and spilled the Q fragments: 16 registers of scratch and a vmcnt(0) in front of every reload, which also
+    // drained the LDS-DMA queue once per tile).
+    auto tile = [&](int j, auto first_c, auto masked_c) {
+        constexpr bool FIRST = decltype(first_c)::value, MASKED = decltype(masked_c)::value;
+        const char *sk, *sv;
+        int nbuf_now;
+        tile_begin(sk, sv, nbuf_now);
+        const int jn = j + RING - 1 < ntile ? j + RING - 1 : ntile - 1;
+        if (!active) {
+            stage(jn, nbuf_now);
+            return;
+        }
+        V8 fr[2][2];                                  // [buffer][key half | dim half]
+        auto rdK = [&](int bi, int ks) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) fr[bi][sub] = *(const V8*)(sk + (32 * sub + l31) * 128 + (((2 * ks + hi) ^ fsw) * 16));
+        };
+        auto rdV = [&](int bi, int st) {
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) fr[bi][ds] = *(const V8*)(sv + (32 * ds + l31) * 128 + (((2 * st + hi) ^ fsw) * 16));
+        };
+        f32x16 sA[2], sB[2];
+        V8 pA[4], pB[4];
+        float ps0 = 0.f, ps1 = 0.f;
+        // a quarter of a block's softmax: scores s[c >> 1][8 (c & 1) .. + 7] -> p -> the c-th packed operand of the PV MFMAs
+        auto sm_quarter = [&](f32x16 (&s)[2], V8 (&pf)[4], int c) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(s[c >> 1][8 * (c & 1) + e]);
+                const float p1 = __builtin_amdgcn_exp2f(s[c >> 1][8 * (c & 1) + e + 1]);
+                ps0 += p0;
+                ps1 += p1;
+                pf[c][e] = (Tt)p0;
+                pf[c][e + 1] = (Tt)p1;
+            }
+        };
+        auto sm_close = [&](QBlock<DT>& x) {
+            const float psum = ps0 + ps1;
+            x.l_run += psum;
+            x.bad |= !(psum <= limit);
+            ps0 = 0.f;
+            ps1 = 0.f;
+        };
+        rdK(0, 0);
+        const f32x16 initA = splat(A.mneg);
+        // (inside a step the two MFMAs come FIRST -- their fragments were requested a whole step ago -- then the next step's requests and
+        // the softmax quarter, which issue in the shadow of those MFMAs)
+#define MHMR_STEP_SPLIT() __builtin_amdgcn_sched_barrier(0)
+        // ---- section 1: QK_A (no VALU work to hide behind: the next step's fragments are requested BEFORE this step's MFMAs) ----
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            rdK((ks + 1) & 1, ks < 3 ? ks + 1 : 0);                   // (the last step requests QK_B's first fragments)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) sA[sub] = Op<DT>::mfma32(fr[ks & 1][sub], A.qf[ks], ks == 0 ? initA : sA[sub]);
+            if (ks == 0) stage(jn, nbuf_now);                        // the next tile's DMA behind the first MFMAs
+            MHMR_STEP_SPLIT();
+        }
+        if constexpr (MASKED) mask_block(sA, j);
+        if constexpr (FIRST) level_block(A, sA);
+        if constexpr (MASKED || FIRST) __builtin_amdgcn_sched_barrier(0);
+        const f32x16 initB = splat(Bq.mneg);
+        // ---- section 2: QK_B beside softmax_A ----
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) sB[sub] = Op<DT>::mfma32(fr[ks & 1][sub], Bq.qf[ks], ks == 0 ? initB : sB[sub]);
+            MHMR_STEP_SPLIT();
+            if (ks < 3) rdK((ks + 1) & 1, ks + 1);
+            else rdV(0, 0);
+            sm_quarter(sA, pA, ks);
+            MHMR_STEP_SPLIT();
+        }
+        sm_close(A);
+        if constexpr (MASKED) mask_block(sB, j);
+        if constexpr (FIRST) level_block(Bq, sB);
+        if constexpr (MASKED || FIRST) __builtin_amdgcn_sched_barrier(0);
+        // ---- section 3: PV_A beside softmax_B ----
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) A.o[ds] = Op<DT>::mfma32(fr[st & 1][ds], pA[st], A.o[ds]);
+            MHMR_STEP_SPLIT();
+            rdV((st + 1) & 1, st < 3 ? st + 1 : 0);
+            sm_quarter(sB, pB, st);
+            MHMR_STEP_SPLIT();
+        }
+        sm_close(Bq);
+        // ---- section 4: PV_B (requests first, as in section 1) ----
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            if (st < 3) rdV((st + 1) & 1, st + 1);
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) Bq.o[ds] = Op<DT>::mfma32(fr[st & 1][ds], pB[st], Bq.o[ds]);
+            MHMR_STEP_SPLIT();
+        }
+#undef MHMR_STEP_SPLIT
+    };
+    {
+        using TT = std::true_type;
+        using FF = std::false_type;
+        if (nfull > 0) tile(0, TT{}, FF{});
+        else tile(0, TT{}, TT{});
+        for (int j = 1; j < nfull; ++j) tile(j, FF{}, FF{});
+        if (ntile > nfull && nfull > 0) tile(nfull, FF{}, TT{});
+    }
+
+    // ---- the lone last key of T = 64 n + 1 (the class token, stored last): rank-1 update, fp32 p ----
+    float* vl = (float*)(smem + RING * 2 * KV_TILE_BYTES) + w * 64;
+    auto tail_block = [&](QBlock<DT>& x, int kl) {
+        int lane2 = lane;
+        asm volatile("" : "+s"(kl), "+v"(lane2));
+        const int hi2 = lane2 >> 5;
+        const Tt* kp = qk + (row0 + kl) * ldq + C + h * 64 + 8 * hi2;
+        float dot = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const V8 kf = *(const V8*)(kp + 16 * ks);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dot = __builtin_fmaf((float)x.qf[ks][e], (float)kf[e], dot);
+        }
+        dot += __shfl_xor(dot, 32);
+        const float p = __builtin_amdgcn_exp2f(dot + x.mneg);
+        x.bad |= !(p <= limit);
+        if (hi == 0) x.l_run += p;
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const f32x4 v4 = *(const f32x4*)(vl + 32 * ds + 8 * rg + 4 * hi2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x.o[ds][4 * rg + e] = __builtin_fmaf(v4[e], p, x.o[ds][4 * rg + e]);
+            }
+    };
+    if (tail1 && active) {
+        const int kl = T - 1;
+        const int klp = (kl & ~12) | ((kl & 4) << 1) | ((kl & 8) >> 1);          // V^T columns are key-permuted (bits 2 <-> 3)
+        vl[lane] = (float)vt[((size_t)(b * H + h) * 64 + lane) * Tp + klp];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // the strip is written and read by this wave only
+        tail_block(A, kl);
+        tail_block(Bq, kl);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- flags (MODE 1 numbering: 128-query workgroups, one flag per 32-query block), normalise, store ----
+    const int nqt1 = (Tp + 127) / 128, qt1 = 2 * qt + (w >> 1);
+    auto finish_block = [&](QBlock<DT>& x, int blk) {
+        const int first_row = qr0 + 32 * blk;
+        const bool anybad = __any(x.bad);
+        if (lane == 0 && qt1 < nqt1) flags[4 * (bh * nqt1 + qt1) + 2 * (w & 1) + blk] = (anybad && first_row < T) ? 1 : 0;
+        const float l_tot = x.l_run + __shfl_xor(x.l_run, 32);
+        const float inv = first_row < T ? 1.0f / l_tot : 0.f;                    // blocks of padding rows store zeros
+        if (first_row >= Tp) return;
+        int lane3 = lane;
+        asm volatile("" : "+v"(lane3));
+        Tt* op = (Tt*)out_ + (row0 + (first_row + (lane3 & 31))) * C + h * 64 + 4 * (lane3 >> 5);
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                V4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (Tt)(x.o[ds][4 * rg + e] * inv);
+                *(V4*)(op + 32 * ds + 8 * rg) = v;
+            }
+    };
+    finish_block(A, 0);
+    finish_block(Bq, 1);
+}
+
+template <int RING>
+int launch_attn64(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit, int* flags,
+                  hipStream_t s) {
+    const int nqt = (Tp + 255) / 256;
+    const int grid = nqt * H * B;
+    const size_t lds = RING * 2 * KV_TILE_BYTES + 4 * 256;
+    if (dtype == MHMR_DT_F16)
+        hipLaunchKernelGGL((attn64_kernel<MHMR_DT_F16, RING>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags);
+    else
+        hipLaunchKernelGGL((attn64_kernel<MHMR_DT_BF16, RING>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags);
+    return 0;
+}
+
 template <int NW, int RING, int MODE>
 int launch_attn(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit, int* flags,
                 hipStream_t s) {
@@ -359,7 +675,7 @@ int mhmr_attention_flag_count_impl(int B, int Tp, int H) { return 4 * ((Tp + 127
 // limit_log2 (variant 0): a workgroup is recomputed by the textbook kernel when a lane's tile sum of exp2(s - level) exceeded
 // 2^limit_log2 (0 <= limit_log2 <= 15; 15 = the shipped value "would leave the 16-bit range", 0 = nearly every workgroup).
 // variant: 0 = MODE 3 + gated MODE 1 fallback (needs `flags`), 1 = textbook (MODE 1), 2 = banded running maximum (MODE 2),
-// 3 = MODE 2 with 8-wave workgroups.
+// 3 = MODE 2 with 8-wave workgroups, 4 / 5 = 64 queries per wave (attn64_kernel, MODE 3 arithmetic + gated fallback; needs `flags`).
 // Measured at ViT-L 896 b32, f16 / bf16 TFLOP/s (tools/kbench.py, interleaved rounds): textbook 855-875 / 895-929; banded
 // maximum 930-940 / 973-1003; the same with the level as a 16-register C tuple (3 waves per SIMD) 918-920 / 975; with all 8 K
 // fragments and the V^T fragments requested ahead of their MFMAs (sched_barrier-pinned; 3 waves per SIMD, or 4 with spills)
@@ -380,6 +696,14 @@ int mhmr_launch_attention_ex(const void* qk, const void* vt, void* out, int B, i
         case 1: launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, nullptr, s); break;
         case 2: launch_attn<4, 2, 2>(qk, vt, out, B, T, Tp, C, H, dtype, limit, nullptr, s); break;
         case 3: launch_attn<8, 3, 2>(qk, vt, out, B, T, Tp, C, H, dtype, limit, nullptr, s); break;
+        case 4:
+        case 5: {     // 64 queries per wave (attn64_kernel) + the gated textbook fallback; 4: 3-slot K/V ring, 5: 2-slot ring
+            if (flags == nullptr) return MHMR_ERR_BAD_ARG;
+            if (variant == 4) launch_attn64<3>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
+            else launch_attn64<2>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
+            launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
+            break;
+        }
         default: return MHMR_ERR_BAD_ARG;
     }
     prof_end(PROF_ATTN, s, 4.0 * B * H * (double)T * T * 64);
@@ -390,6 +714,6 @@ int mhmr_launch_attention_ex(const void* qk, const void* vt, void* out, int B, i
 int mhmr_launch_attention(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, int* flags,
                           hipStream_t s) {
     static const char* v = getenv("MHMR_ATTN_VARIANT");      // A/B measurements only
-    const int variant = v ? atoi(v) : (flags ? 0 : 2);
+    const int variant = v ? atoi(v) : (flags ? MHMR_ATTN_DEFAULT_VARIANT : 2);
     return mhmr_launch_attention_ex(qk, vt, out, B, T, Tp, C, H, dtype, 15.f, variant, flags, s);
 }

@@ -24,6 +24,9 @@ int mhmr_launch_hph_inputs(const float* feat32, const float* zK, const int* det_
 int mhmr_launch_hph_self_attn(const float* qkv, const int* gstart, float* out, int ngroups, int nmax, int heads, hipStream_t s);
 int mhmr_launch_hph_cross_attn(const float* q, const float* kv, const int* chunks, int nchunks, float* out, int heads, int N, hipStream_t s);
 int mhmr_launch_hph_decode(const float* dec, int ldd, int nb, const float* Kmat, const int* det_b, float fn, int nearness, float* rotmat, float* rotvec, float* betas, float* expr, float* dist_pp, float* dist, int P, hipStream_t s);
+int mhmr_launch_cls_linear(const void* A, long long a_stride, const void* W, int ldw, int B, int N, int K, int a_k, const float* bias,
+                           const float* gamma, void* out, long long o_stride, int n_base, int C, void* vt, int H, int Tp, int vcol, int epi,
+                           int dtype, hipStream_t s);
 int mhmr_launch_loc(const float* offset, const int* det_y, const int* det_x, int patch, float* loc, int P, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------ profiler
@@ -101,6 +104,23 @@ int mhmr_gemm16(const void* A, int lda, const void* W, int ldw, int M, int N, in
     return mhmr_launch_gemm(g, dtype, (hipStream_t)stream);
 }
 
+int mhmr_gemm16_ex(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, const float* gamma,
+                   void* out, int ldo, const float* pos, int Np, int Tp, int H, int Mvalid, int epi, int dtype, int img_rows, int img_stride,
+                   int a_k, void* stream) {
+    GemmArgs g{A, lda, W, ldw, M, N, K, bias, gamma, out, ldo, pos, Np, Tp, H, Mvalid, epi};
+    g.img_rows = img_rows;
+    g.img_stride = img_stride;
+    g.a_k = a_k;
+    return mhmr_launch_gemm(g, dtype, (hipStream_t)stream);
+}
+
+int mhmr_cls_linear16(const void* A, long long a_stride, const void* W, int ldw, int B, int N, int K, int a_k, const float* bias,
+                      const float* gamma, void* out, long long o_stride, int n_base, int C, void* vt, int H, int Tp, int vcol, int epi,
+                      int dtype, void* stream) {
+    return mhmr_launch_cls_linear(A, a_stride, W, ldw, B, N, K, a_k, bias, gamma, out, o_stride, n_base, C, vt, H, Tp, vcol, epi, dtype,
+                                  (hipStream_t)stream);
+}
+
 int mhmr_attention16(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, void* stream) {
     return mhmr_launch_attention(qk, vt, out, B, T, Tp, C, H, dtype, nullptr, (hipStream_t)stream);
 }
@@ -123,26 +143,19 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
         d->C != d->H * 64 || d->Kp % 64 || d->Kp < 588 || (d->C != 384 && d->C != 768 && d->C != 1024))
         return MHMR_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    const int dt = d->dtype, B = d->B, C = d->C, Tp = d->Tp, M = B * Tp;
-    const int Mp = (B * d->N + 127) / 128 * 128;
-    // side stream for the V projection (below).  One process drives one GPU: the stream belongs to the device that was
-    // current at the first call; a call on another device, MHMR_QKV_OVERLAP=0 or an active profiling window run serialized.
-    static struct Side {
-        bool on = false;
-        int dev = -1;
-        hipStream_t stream = nullptr;
-        hipEvent_t fork = nullptr, join = nullptr;
-        Side() {
-            const char* e = getenv("MHMR_QKV_OVERLAP");
-            if (!e || atoi(e) != 0)
-                on = hipGetDevice(&dev) == hipSuccess && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
-                     hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
-                     hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
-        }
-    } side;
-    int cur_dev = -1;
-    const bool overlap = side.on && g_prof.kind < 0 && hipGetDevice(&cur_dev) == hipSuccess && cur_dev == side.dev;
+    const int dt = d->dtype, B = d->B, C = d->C, N = d->N, Tp = d->Tp, M = B * Tp;
+    const int Mp = (B * N + 127) / 128 * 128;
+    // Token rows of an image: patches 0..N-1, the class token at row N, zero padding up to Tp (vit_misc.hip).  When the patch rows of
+    // an image are whole 256-row tiles and every linear runs on the 256x256 kernel, the five big GEMMs of a block cover the B * N
+    // patch rows only (GemmArgs::img_rows: exact tile rounds) and the B class rows go through the skinny kernel (vit_cls.hip);
+    // otherwise one GEMM covers all B * Tp rows.  MHMR_ROWMAP=0 forces the latter (A/B measurements).  Everything is launched on the
+    // caller's stream: the call is re-entrant across streams and capturable.
+    static const bool rowmap_env = !(getenv("MHMR_ROWMAP") && atoi(getenv("MHMR_ROWMAP")) == 0);
+    const bool rowmap = rowmap_env && C % 256 == 0 && N % 256 == 0 && (uint64_t)M * (uint64_t)C * 4u < (1ull << 32);
+    const int Mg = rowmap ? B * N : M, ir = rowmap ? N : 0, is = rowmap ? Tp : 0;
     const size_t esz = 2;
+    const long long cls_row = (long long)N;                          // the class row inside an image
+    const int vcol = (N & ~12) | ((N & 4) << 1) | ((N & 8) >> 1);    // its (key-permuted) V^T column
 
     // tokens: patch embedding (im2col + GEMM with bias / pos-embed epilogue), class + padding rows
     TRY(mhmr_launch_im2col(x, d->a_patch, B, d->S, d->G, d->Kp, dt, s));
@@ -152,40 +165,64 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
                    B * d->N, EPI_PATCH};
         TRY(mhmr_launch_gemm(g, dt, s));
     }
+    auto rows = [&](GemmArgs& g) { g.img_rows = ir; g.img_stride = is; };
     for (int l = 0; l < d->L; ++l) {
         const mhmr_vit_block& k = d->blocks[l];
+        // the V and output projections may carry the low halves of their weights ([W_hi | W_lo] along k, one accumulator chain)
+        const void* v_w = k.v_w2 ? k.v_w2 : (const void*)((const char*)k.qkv_w + (size_t)2 * C * C * esz);
+        const int v_k = k.v_w2 ? 2 * C : C, v_ak = k.v_w2 ? C : 0;
+        const void* p_w = k.proj_w2 ? k.proj_w2 : k.proj_w;
+        const int p_k = k.proj_w2 ? 2 * C : C, p_ak = k.proj_w2 ? C : 0;
         // x = x + ls1 * proj(MHSA(norm1(x)))
         TRY(mhmr_launch_layernorm(d->resid, k.ln1_w, k.ln1_b, d->xn, M, C, 1e-6f, dt, s));
         {
-            GemmArgs g{d->xn, C, k.qkv_w, C, M, 2 * C, C, k.qkv_b, nullptr, d->qk, 2 * C, nullptr, 0, Tp, d->H, M, EPI_OP16_QK};
-            GemmArgs gv{d->xn, C, (const char*)k.qkv_w + (size_t)2 * C * C * esz, C, M, C, C, k.qkv_b + 2 * C, nullptr, d->vt, 0,
-                        nullptr, 0, Tp, d->H, M, EPI_VT};
-            if (overlap) {
-                // the two projections read the same xn and are independent: V goes to a side stream, so that the CUs that run out
-                // of V tiles (8.1 rounds of 256 paid as 9) start on QK tiles instead of idling (16.25 rounds paid as 17):
-                // 140.3 -> 139.7 ms per forward at ViT-L 896 x 32 (A/B in one process environment, two runs each)
-                if (hipEventRecord(side.fork, s) != hipSuccess || hipStreamWaitEvent(side.stream, side.fork, 0) != hipSuccess) return MHMR_ERR_BAD_ARG;
-                TRY(mhmr_launch_gemm(gv, dt, side.stream));
-                if (hipEventRecord(side.join, side.stream) != hipSuccess) return MHMR_ERR_BAD_ARG;
-                TRY(mhmr_launch_gemm(g, dt, s));
-                if (hipStreamWaitEvent(s, side.join, 0) != hipSuccess) return MHMR_ERR_BAD_ARG;
-            } else {
-                TRY(mhmr_launch_gemm(g, dt, s));
-                TRY(mhmr_launch_gemm(gv, dt, s));
+            GemmArgs g{d->xn, C, k.qkv_w, C, Mg, 2 * C, C, k.qkv_b, nullptr, d->qk, 2 * C, nullptr, 0, Tp, d->H, Mg, EPI_OP16_QK};
+            GemmArgs gv{d->xn, C, v_w, v_k, Mg, C, v_k, k.qkv_b + 2 * C, nullptr, d->vt, 0, nullptr, 0, Tp, d->H, Mg, EPI_VT};
+            gv.a_k = v_ak;
+            rows(g); rows(gv);
+            TRY(mhmr_launch_gemm(g, dt, s));
+            TRY(mhmr_launch_gemm(gv, dt, s));
+            if (rowmap) {
+                const char* xr = (const char*)d->xn + (size_t)cls_row * C * esz;
+                char* qr = (char*)d->qk + (size_t)cls_row * 2 * C * esz;
+                if (k.v_w2) {
+                    TRY(mhmr_launch_cls_linear(xr, (long long)Tp * C, k.qkv_w, C, B, 2 * C, C, 0, k.qkv_b, nullptr, qr, (long long)Tp * 2 * C, 0, C,
+                                               d->vt, d->H, Tp, vcol, 0, dt, s));
+                    TRY(mhmr_launch_cls_linear(xr, (long long)Tp * C, v_w, v_k, B, C, v_k, v_ak, k.qkv_b + 2 * C, nullptr, qr, (long long)Tp * 2 * C,
+                                               2 * C, C, d->vt, d->H, Tp, vcol, 0, dt, s));
+                } else {
+                    TRY(mhmr_launch_cls_linear(xr, (long long)Tp * C, k.qkv_w, C, B, 3 * C, C, 0, k.qkv_b, nullptr, qr, (long long)Tp * 2 * C, 0, C,
+                                               d->vt, d->H, Tp, vcol, 0, dt, s));
+                }
             }
         }
         TRY(mhmr_launch_attention(d->qk, d->vt, d->att, B, d->T, Tp, C, d->H, dt, d->attn_flags, s));
         {
-            GemmArgs g{d->att, C, k.proj_w, C, M, C, C, k.proj_b, k.ls1, d->resid, C, nullptr, 0, Tp, d->H, M, EPI_RESID};
+            GemmArgs g{d->att, C, p_w, p_k, Mg, C, p_k, k.proj_b, k.ls1, d->resid, C, nullptr, 0, Tp, d->H, Mg, EPI_RESID};
+            g.a_k = p_ak;
+            rows(g);
             TRY(mhmr_launch_gemm(g, dt, s));
+            if (rowmap)
+                TRY(mhmr_launch_cls_linear((const char*)d->att + (size_t)cls_row * C * esz, (long long)Tp * C, p_w, p_k, B, C, p_k, p_ak, k.proj_b,
+                                           k.ls1, d->resid + (size_t)cls_row * C, (long long)Tp * C, 0, C, nullptr, d->H, Tp, 0, 1, dt, s));
         }
         // x = x + ls2 * fc2(gelu(fc1(norm2(x))))
         TRY(mhmr_launch_layernorm(d->resid, k.ln2_w, k.ln2_b, d->xn, M, C, 1e-6f, dt, s));
         {
-            GemmArgs g{d->xn, C, k.fc1_w, C, M, 4 * C, C, k.fc1_b, nullptr, d->hid, 4 * C, nullptr, 0, Tp, d->H, M, EPI_OP16_GELU};
+            GemmArgs g{d->xn, C, k.fc1_w, C, Mg, 4 * C, C, k.fc1_b, nullptr, d->hid, 4 * C, nullptr, 0, Tp, d->H, Mg, EPI_OP16_GELU};
+            rows(g);
             TRY(mhmr_launch_gemm(g, dt, s));
-            GemmArgs g2{d->hid, 4 * C, k.fc2_w, 4 * C, M, C, 4 * C, k.fc2_b, k.ls2, d->resid, C, nullptr, 0, Tp, d->H, M, EPI_RESID};
+            if (rowmap)
+                TRY(mhmr_launch_cls_linear((const char*)d->xn + (size_t)cls_row * C * esz, (long long)Tp * C, k.fc1_w, C, B, 4 * C, C, 0, k.fc1_b,
+                                           nullptr, (char*)d->hid + (size_t)cls_row * 4 * C * esz, (long long)Tp * 4 * C, 0, C, nullptr, d->H, Tp, 0,
+                                           2, dt, s));
+            GemmArgs g2{d->hid, 4 * C, k.fc2_w, 4 * C, Mg, C, 4 * C, k.fc2_b, k.ls2, d->resid, C, nullptr, 0, Tp, d->H, Mg, EPI_RESID};
+            rows(g2);
             TRY(mhmr_launch_gemm(g2, dt, s));
+            if (rowmap)
+                TRY(mhmr_launch_cls_linear((const char*)d->hid + (size_t)cls_row * 4 * C * esz, (long long)Tp * 4 * C, k.fc2_w, 4 * C, B, C, 4 * C,
+                                           0, k.fc2_b, k.ls2, d->resid + (size_t)cls_row * C, (long long)Tp * C, 0, C, nullptr, d->H, Tp, 0, 1, dt,
+                                           s));
         }
     }
     return mhmr_launch_final_norm(d->resid, d->norm_w, d->norm_b, ctx16, ldctx, feat32, B, d->N, Tp, C, 1e-6f, dt, s);

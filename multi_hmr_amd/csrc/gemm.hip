@@ -40,14 +40,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     // ---- staging addresses (per thread constant; advance by BK per K tile) ----
     const int srow = tid >> 3;                                   // 0..31 (+32 per pass)
     const int schunk = (tid & 7) ^ ((tid >> 4) & 7);             // logical chunk landing at phys chunk tid&7
-    const T* a_src = (const T*)g.A + (size_t)(m0 + srow) * g.lda + schunk * 8;
+    const int m0p = (int)mhmr_phys_row(m0, g.img_rows, g.img_stride);      // physical first activation / output row (mhmr_internal.h)
+    const T* a_src = (const T*)g.A + (size_t)(m0p + srow) * g.lda + schunk * 8;
     const T* w_src = (const T*)g.W + (size_t)(n0 + srow) * g.ldw + schunk * 8;
     const size_t a_pass = (size_t)32 * g.lda, w_pass = (size_t)32 * g.ldw;
 
+    const int nta = g.a_k > 0 ? g.a_k / BK : g.K / BK;
     auto stage = [&](int kt, int buf) {
         char* sa = smem + buf * (2 * TILE_BYTES) + w * 1024;
         char* sw = sa + TILE_BYTES;
-        const T* ap = a_src + kt * BK;
+        const T* ap = a_src + (kt >= nta ? kt - nta : kt) * BK;            // low-half weight pass: the activation's k tiles wrap around
         const T* wp = w_src + kt * BK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     if constexpr (ROWMAJOR) {
         __syncthreads();  // every wave is done reading the last K tile
         char* wl = smem + w * 16384;
-        const int mb = m0 + 64 * wq_, nb = n0 + 64 * wp_;
+        const int mb = m0p + 64 * wq_, nb = n0 + 64 * wp_;
         constexpr bool OUT16 = (EPI == EPI_OP16 || EPI == EPI_OP16_GELU || EPI == EPI_OP16_RELU || EPI == EPI_OP16_QK);
         if constexpr (OUT16) {
             // bias + activation + convert here (lane owns 4 consecutive n), LDS rows = 64 n x 2 B = 128 B
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                     if (m < g.Mvalid) {
                         const int b = m / g.Np, n_in = m - b * g.Np;
                         v += *(const f32x4*)(g.pos + (size_t)(1 + n_in) * g.N + n);
-                        *(f32x4*)((float*)g.out + ((size_t)b * g.Tp + 1 + n_in) * g.ldo + n) = v;
+                        *(f32x4*)((float*)g.out + ((size_t)b * g.Tp + n_in) * g.ldo + n) = v;      // class token LAST: patch n at row n
                     }
                 } else {  // EPI_F32
                     *(f32x4*)((float*)g.out + (size_t)m * g.ldo + n) = v;
@@ -183,7 +185,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         }
     } else {
         // V^T: vt[((b*H + h)*64 + d) * Tp + swap23(t)], 4 consecutive tokens per lane (8-byte store)
-        const int b = m0 / g.Tp, t0 = m0 - b * g.Tp;
+        const int rpi = g.img_rows > 0 ? g.img_rows : g.Tp;
+        const int b = m0 / rpi, t0 = m0 - b * rpi;
 #pragma unroll
         for (int qj = 0; qj < 2; ++qj) {
             const int n = n0 + 64 * wq_ + 32 * qj + l31;
@@ -249,7 +252,9 @@ int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % BM || g.N % BN || g.K % BK) return MHMR_ERR_BAD_SHAPE;
     if (g.lda % 8 || g.ldw % 8) return MHMR_ERR_BAD_SHAPE;
     if (g.epi == EPI_VT && (g.Tp % 64 || g.N % 64)) return MHMR_ERR_BAD_SHAPE;
-    if (g.epi == EPI_VT && g.Tp % BM && (g_force_gemm128 || !mhmr_gemm256_eligible(g))) return MHMR_ERR_BAD_SHAPE;   // (this kernel's row tile)
+    if (g.epi == EPI_VT && (g.img_rows > 0 ? g.img_rows : g.Tp) % BM && (g_force_gemm128 || !mhmr_gemm256_eligible(g))) return MHMR_ERR_BAD_SHAPE;   // (this kernel's row tile)
+    if (g.img_rows > 0 && (g.img_rows % BM || g.M % g.img_rows || g.img_stride < g.img_rows || g.epi == EPI_PATCH)) return MHMR_ERR_BAD_SHAPE;
+    if (g.a_k > 0 && (g.a_k % BK || g.K != 2 * g.a_k || g.ldw < g.K)) return MHMR_ERR_BAD_SHAPE;
     if (g.epi == EPI_OP16_QK && g.N % 128) return MHMR_ERR_BAD_SHAPE;      // Q | K halves are whole 64-column blocks
     prof_begin(PROF_GEMM, s);
     int rc;
@@ -262,6 +267,9 @@ int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s) {
         static const char* st = getenv("MHMR_STAGGER_PCT");
         if (g.epi == EPI_RESID && (g.M / 256) * (g.N / 256) >= 1024)      // only when every CU walks several tiles
             g2.stagger_ticks = (int)((g.K / 64 * 1.4 + 18.0) * 25.0 * (st ? atoi(st) : 100) / 100.0);
+        static const char* cg = getenv("MHMR_COLGROUP");
+        g2.colgroup = cg ? atoi(cg) : 1;
+        if (g.img_rows > 0) g2.img_magic = (unsigned)((1ull << 32) / (unsigned)(g.img_rows >> 8)) + 1u;     // exact while tm * tiles_per_image < 2^32
         rc = mhmr_launch_gemm256(g2, dtype, s);
     }
     else rc = dtype == MHMR_DT_F16 ? launch_dt<MHMR_DT_F16>(g, s) : launch_dt<MHMR_DT_BF16>(g, s);

@@ -61,21 +61,37 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     const int nbn = g.N / 256, ntiles = (g.M / 256) * nbn;
     const int G = gridDim.x, b = blockIdx.x;
     const int first = (G & 7) == 0 ? (b & 7) * (G >> 3) + (b >> 3) : b;
+    // Column-group order (wide outputs: QK N = 2048, fc1 N = 4096): an XCD keeps the SAME four weight column panels in every round
+    // (2 MB of W stay in its L2 for the whole launch) and walks 8 row tiles of them per round, instead of 2 row tiles x all 16
+    // column panels (every XCD re-fetched the whole 8 MB of fc1's W each round: 2.5 GB per launch for 0.28 GB of operands).
+    const int ncg = nbn >> 2;                                         // column groups of 4 panels
+    const bool colgroup = g.colgroup && G == 256 && (nbn & 3) == 0 && ncg > 1 && ncg <= 8 && (8 % ncg) == 0;
 
     // ---- DMA source addressing: one half-tile = 2 passes of 64 rows; lane-linear LDS image, swizzle on the source ----
     const int srow = tid >> 3;                                  // 0..63
     const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
     const int nt = g.K / 64;
+    const int nta = g.a_k > 0 ? g.a_k / 64 : nt;                     // k tiles of the activation operand (low-half weight pass: nt = 2 nta)
+    auto ka = [&](int t) { return t >= nta ? t - nta : t; };
     // an operand position = a wave-uniform 64-bit TILE base (scalar registers; any M x K) + a 32-bit element offset inside the tile
     // (< 256 rows: fits for every ld below 2^22): half the vector registers of per-lane 64-bit pointers
     const uint32_t p_lane = (uint32_t)srow * (uint32_t)ldp + (uint32_t)(schunk * 8);
     const uint32_t q_lane = (uint32_t)srow * (uint32_t)ldq + (uint32_t)(schunk * 8);
-    auto tile_src = [&](int tix, const T*& pb, const T*& qb, int& p0, int& q0) {
+    // p0 / q0: LOGICAL first index of the tile on the P / Q side; ar: PHYSICAL first row of its activation rows (GemmArgs::img_rows)
+    // (the image of a row tile by a host-made reciprocal, GemmArgs::img_magic: a run-time integer division here costs a dozen live
+    // vector registers in a kernel that has none to spare)
+    auto tile_src = [&](int tix, const T*& pb, const T*& qb, int& p0, int& q0, int& ar, int& bimg) {
         const int tn = tix % nbn, tm = tix / nbn;
         p0 = ROWMAJOR ? tn * 256 : tm * 256;
         q0 = ROWMAJOR ? tm * 256 : tn * 256;
-        pb = Pm + (size_t)p0 * (size_t)ldp;
-        qb = Qm + (size_t)q0 * (size_t)ldq;
+        bimg = 0;
+        ar = tm * 256;
+        if (g.img_rows > 0) {
+            bimg = (int)__umulhi((unsigned)tm, g.img_magic);
+            ar = bimg * g.img_stride + (tm - bimg * (g.img_rows >> 8)) * 256;
+        }
+        pb = Pm + (size_t)(ROWMAJOR ? p0 : ar) * (size_t)ldp;
+        qb = Qm + (size_t)(ROWMAJOR ? ar : q0) * (size_t)ldq;
     };
     auto dma = [&](const T* base, uint32_t lane_off, int ld, int half, int kt, int lds_off) {
         const uint32_t o = lane_off + (uint32_t)(128 * half) * (uint32_t)ld + (uint32_t)(kt * 64);
@@ -137,13 +153,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     };
 
     const T *p_src, *q_src, *p_nxt, *q_nxt;
-    int p0, q0, p0n, q0n;
+    int p0, q0, p0n, q0n, ar, arn, bimg, bimgn;
     if (first >= ntiles) return;             // (never with the launcher's grid: G <= ntiles; keeps barrier counts trivially equal)
     if (g.stagger_ticks > 0) {       // CU quarters start 0/1/2/3 x stagger_ticks late so their epilogue bursts interleave (gemm.hip)
         const uint64_t t0 = wall_clock64(), dl = (uint64_t)g.stagger_ticks * (uint64_t)(first * 4 / G);
         while (wall_clock64() - t0 < dl) __builtin_amdgcn_s_sleep(32);
     }
-    tile_src(first, p_src, q_src, p0, q0);
+    // this workgroup's tiles: one per full round, and the tiles of the last, partial round go to the LOWEST block
+    // indices (b < ntiles % G): when another persistent launch is draining beside this one, the workgroups dispatched first are
+    // then the ones with the extra tile
+    const int full = ntiles / G, nmine = full + (b < ntiles - full * G ? 1 : 0);
+    auto tile_of = [&](int r) {
+        if (r >= full) return full * G + b;
+        if (colgroup) {
+            const int x = b & 7, slot = b >> 3;                       // XCD (speed only), slot 0..31 inside it
+            const int row = r * (G / nbn) + (x / ncg) * 8 + (slot >> 2), col = (x % ncg) * 4 + (slot & 3);
+            return row * nbn + col;
+        }
+        return first + r * G;
+    };
+    tile_src(tile_of(0), p_src, q_src, p0, q0, ar, bimg);
 
     // ---- prologue (first tile only): K tile 0 -> even buffer (all four halves), K tile 1 -> odd buffer (Q1, P0, Q0; P1 follows
     //      in phase 1 like in every later pair) ----
@@ -159,57 +188,54 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MHMR_SYNC();
 
-    // this workgroup's tiles: one per full round at `first`, and the tiles of the last, partial round go to the LOWEST block
-    // indices (b < ntiles % G): when another persistent launch is draining beside this one, the workgroups dispatched first are
-    // then the ones with the extra tile
-    const int full = ntiles / G, nmine = full + (b < ntiles - full * G ? 1 : 0);
-    auto tile_of = [&](int r) { return r < full ? first + r * G : full * G + b; };
     for (int r = 0; r < nmine; ++r) {
-        const int tix = tile_of(r);
         // Q0 of this tile's first K tile (landed and published by the previous pair's phase-8 wait + barrier, or by the prologue)
         rdQ(QA, 0, SLOT_Q0);
         if (wp == 1) { MHMR_SYNC(); }       // stagger: during the K loop group 1 runs one barrier behind group 0
         const bool has_next = r + 1 < nmine;
-        if (has_next) tile_src(tile_of(r + 1), p_nxt, q_nxt, p0n, q0n);
-        else { p_nxt = p_src; q_nxt = q_src; p0n = p0; q0n = q0; }     // last tile: harmless re-load into slots nobody reads
+        if (has_next) tile_src(tile_of(r + 1), p_nxt, q_nxt, p0n, q0n, arn, bimgn);
+        else { p_nxt = p_src; q_nxt = q_src; p0n = p0; q0n = q0; arn = ar; bimgn = bimg; }     // last tile: harmless re-load into slots nobody reads
         for (int t = 0; t < nt; t += 2) {
             // K-tile indices past the end of this tile are the first K tiles of the next one
             const bool wrap = t + 2 >= nt;
             const T* p2 = wrap ? p_nxt : p_src;
             const T* q2 = wrap ? q_nxt : q_src;
             const int t1 = t + 1, t2 = wrap ? (has_next ? 0 : nt - 1) : t + 2, t3 = wrap ? (has_next ? 1 : nt - 1) : t + 3;
+            // the activation side (Q for row-major outputs, P for V^T) wraps around at nta k tiles (low-half weight pass)
+            const int t1p = ROWMAJOR ? t1 : ka(t1), t2p = ROWMAJOR ? t2 : ka(t2), t3p = ROWMAJOR ? t3 : ka(t3);
+            const int t2q = ROWMAJOR ? ka(t2) : t2, t3q = ROWMAJOR ? ka(t3) : t3;
             // phase 1
             rdP(0, SLOT_P0);
-            dma(p_src, p_lane, ldp, 1, t1, BUF + SLOT_P1); MHMR_WAIT_DMA();
+            dma(p_src, p_lane, ldp, 1, t1p, BUF + SLOT_P1); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[0][0], QA); MHMR_SYNC();
             // phase 2
             rdQ(QB, 0, SLOT_Q1);
-            dma(q2, q_lane, ldq, 0, t2, SLOT_Q0); MHMR_WAIT_DMA();
+            dma(q2, q_lane, ldq, 0, t2q, SLOT_Q0); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[0][1], QB); MHMR_SYNC();
             // phase 3
             rdP(0, SLOT_P1);
-            dma(p2, p_lane, ldp, 0, t2, SLOT_P0); MHMR_WAIT_DMA();
+            dma(p2, p_lane, ldp, 0, t2p, SLOT_P0); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[1][1], QB); MHMR_SYNC();
             // phase 4
             rdQ(QB, 1, SLOT_Q1);
-            dma(q2, q_lane, ldq, 1, t2, SLOT_Q1); MHMR_WAIT_DMA();
+            dma(q2, q_lane, ldq, 1, t2q, SLOT_Q1); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[1][0], QA); MHMR_SYNC();
             // phase 5
             rdP(1, SLOT_P0);
-            dma(p2, p_lane, ldp, 1, t2, SLOT_P1); MHMR_WAIT_DMA();
+            dma(p2, p_lane, ldp, 1, t2p, SLOT_P1); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[0][1], QB); MHMR_SYNC();
             // phase 6
             rdQ(QA, 1, SLOT_Q0);
-            dma(q2, q_lane, ldq, 1, t3, BUF + SLOT_Q1); MHMR_WAIT_DMA();
+            dma(q2, q_lane, ldq, 1, t3q, BUF + SLOT_Q1); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[0][0], QA); MHMR_SYNC();
             // phase 7
             rdP(1, SLOT_P1);
-            dma(p2, p_lane, ldp, 0, t3, BUF + SLOT_P0); MHMR_WAIT_DMA();
+            dma(p2, p_lane, ldp, 0, t3p, BUF + SLOT_P0); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[1][0], QA); MHMR_SYNC();
             // phase 8 (the next pair's Q0; at the end of a tile it is read after the epilogue instead, so that QA's registers are
             // free for the epilogue)
             if (!wrap) rdQ(QA, 0, SLOT_Q0);
-            dma(q2, q_lane, ldq, 0, t3, BUF + SLOT_Q0); MHMR_WAIT_DMA();
+            dma(q2, q_lane, ldq, 0, t3q, BUF + SLOT_Q0); MHMR_WAIT_DMA();
             MHMR_SYNC(); mma(acc[1][1], QB); MHMR_SYNC();
         }
 
@@ -231,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
             constexpr int RD = 1;
             const int c = lane & 15;
             // 32-bit byte offsets from the uniform base (eligibility guarantees M * ldo * 4 < 2^32): one VGPR per address
-            const uint32_t off0 = ((uint32_t)(q0 + 32 * wq + (lane >> 4)) * (uint32_t)g.ldo + (uint32_t)(p0 + 64 * wp + 4 * c)) * 4u;
+            const uint32_t off0 = ((uint32_t)(ar + 32 * wq + (lane >> 4)) * (uint32_t)g.ldo + (uint32_t)(p0 + 64 * wp + 4 * c)) * 4u;
             const uint32_t rstep = (uint32_t)g.ldo * 16u;          // 4 rows
             auto rptr = [&](int sidx, int it) {
                 const int h = sidx >> 2, j = (sidx >> 1) & 1, qs = sidx & 1;
@@ -268,8 +294,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int pb = p0 + 128 * h + 64 * wp;      // first P index of the block (n for row-major, token for V^T)
-                const int qb = q0 + 128 * j + 32 * wq;      // first Q index (m for row-major, channel for V^T)
+                const int pb = p0 + 128 * h + 64 * wp;      // first P index of the block (n for row-major, LOGICAL token row for V^T)
+                const int qb = q0 + 128 * j + 32 * wq;      // first Q index (logical m for row-major, channel for V^T)
+                const int qphys = ar + 128 * j + 32 * wq;   // row-major outputs: physical row of qb
                 if constexpr (OUT16) {
                     const float qscale = (EPI == EPI_OP16_QK && pb < (g.N >> 1)) ? MHMR_ATTN_QSCALE : 1.f;   // 64 columns: all Q or all K
 #pragma unroll
@@ -299,9 +326,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                         const int row = 8 * it + (lane >> 3), c16 = lane & 7;
                         const u32x4 v = *(const u32x4*)(wl + row * 128 + ((c16 ^ (row & 7)) * 16));
                         if constexpr (ROWMAJOR) {
-                            *(u32x4*)((T*)g.out + (size_t)(qb + row) * g.ldo + pb + c16 * 8) = v;
+                            *(u32x4*)((T*)g.out + (size_t)(qphys + row) * g.ldo + pb + c16 * 8) = v;
                         } else {
-                            const int n = qb + row, bi = pb / g.Tp, tl = pb - bi * g.Tp;
+                            // image and token-in-image of the block's first (logical) token row
+                            const int n = qb + row, bi = g.img_rows > 0 ? bimg : pb / g.Tp, tl = pb - bi * (g.img_rows > 0 ? g.img_rows : g.Tp);
                             *(u32x4*)((T*)g.out + ((size_t)(bi * g.H + (n >> 6)) * 64 + (n & 63)) * g.Tp + tl + c16 * 8) = v;
                         }
                     }
@@ -325,10 +353,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                                 if (m < g.Mvalid) {
                                     const int bi = m / g.Np, n_in = m - bi * g.Np;
                                     v += *(const f32x4*)(g.pos + (size_t)(1 + n_in) * g.N + n);
-                                    *(f32x4*)((float*)g.out + ((size_t)bi * g.Tp + 1 + n_in) * g.ldo + n) = v;
+                                    *(f32x4*)((float*)g.out + ((size_t)bi * g.Tp + n_in) * g.ldo + n) = v;      // class token LAST: patch n at row n
                                 }
                             } else {
-                                *(f32x4*)((float*)g.out + (size_t)m * g.ldo + n) = v;
+                                *(f32x4*)((float*)g.out + (size_t)(qphys + 16 * qs + row) * g.ldo + n) = v;
                             }
                         }
                     }
@@ -338,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         }
         // drain: the epilogue's stores and the (long landed) next-tile DMA; re-establishes exact vmcnt accounting
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        p_src = p_nxt; q_src = q_nxt; p0 = p0n; q0 = q0n;
+        p_src = p_nxt; q_src = q_nxt; p0 = p0n; q0 = q0n; ar = arn; bimg = bimgn;
     }
 #undef MHMR_SYNC
 #undef MHMR_WAIT_DMA
@@ -386,7 +414,10 @@ int launch256_dt(const GemmArgs& g, hipStream_t s) {
 }  // namespace
 
 bool mhmr_gemm256_eligible(const GemmArgs& g) {
-    if (g.epi == EPI_RESID && (uint64_t)g.M * (uint64_t)g.ldo * 4u >= (1ull << 32)) return false;   // 32-bit residual offsets
+    const uint64_t mphys = g.img_rows > 0 ? (uint64_t)(g.M / g.img_rows) * (uint64_t)g.img_stride : (uint64_t)g.M;
+    if (g.epi == EPI_RESID && mphys * (uint64_t)g.ldo * 4u >= (1ull << 32)) return false;   // 32-bit residual offsets
+    if (g.img_rows > 0 && (g.img_rows % 256 || g.M % g.img_rows || g.epi == EPI_PATCH)) return false;   // a tile never straddles two images
+    if (g.a_k > 0 && (g.a_k % 128 || g.K != 2 * g.a_k)) return false;
     if (g.lda >= (1 << 22) || g.ldw >= (1 << 22)) return false;      // 32-bit operand offsets INSIDE a 256-row tile (tile bases are 64-bit)
     return g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && (g.epi != EPI_VT || g.Tp % 64 == 0);
 }

@@ -26,7 +26,21 @@ struct GemmArgs {
     int Np, Tp, H, Mvalid;
     int epi;
     int stagger_ticks = 0;   // gemm256: CU quarter q starts q * stagger_ticks (100 MHz wall clock) late
+    // Token-row map of the activation / output rows (ViT blocks): logical row m = b * img_rows + n lives at physical row
+    // b * img_stride + n.  The big linears then run over the B * N patch rows only (exactly 8 / 16 / 32 rounds of 256 tiles at
+    // 896^2 x 32) and skip the class + padding rows of every image (vit_cls.hip computes the class rows).  0 = rows are physical.
+    int img_rows = 0, img_stride = 0;
+    unsigned img_magic = 0;  // floor(2^32 / (img_rows / 256)) + 1, set by mhmr_launch_gemm: image of row tile tm = umulhi(tm, img_magic)
+    // Low-half weight pass: W = [W_hi | W_lo] along k (ldw >= K, K = 2 * a_k): k tiles >= a_k / 64 re-read the activation's k tiles
+    // from the start, so acc = A . W_hi^T + A . W_lo^T in one accumulator chain.  0 = off.
+    int a_k = 0;
+    int colgroup = 0;        // gemm256: column-group tile order for wide outputs (set by mhmr_launch_gemm; MHMR_COLGROUP=0 disables)
 };
+
+// physical row of logical activation row m (see GemmArgs::img_rows)
+__host__ __device__ inline long long mhmr_phys_row(int m, int img_rows, int img_stride) {
+    return img_rows > 0 ? (long long)(m / img_rows) * img_stride + (m % img_rows) : (long long)m;
+}
 
 int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s);
 

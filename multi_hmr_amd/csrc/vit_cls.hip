@@ -1,0 +1,125 @@
+// The CLASS-token rows of the DINOv2 block linears (reference blocks/dinov2.py:16-26 -> DinoVisionTransformer blocks: the class
+// token runs through the same qkv / proj / fc1 / fc2 as the patch tokens).
+//
+// With the class token stored LAST in every image (row b*Tp + N, vit_misc.hip) the big 256x256-tile GEMMs run over the B*N patch
+// rows only -- a whole number of tile rounds (896^2 x 32: 2048 / 4096 / 8192 tiles on 256 CUs) instead of 8.1 / 16.25 / 32.5 rounds
+// paid as 9 / 17 / 33 -- and the B class rows (one per image, Tp rows apart) are computed here: a "skinny" GEMM, M = B <= 32 rows per
+// block pass, which is a weight-streaming problem (2 ... 8 MB of 16-bit weights per linear against 67 ... 268 MFLOP).
+//
+//   grid = (N / 16, ceil(B / 32)); one workgroup = 4 waves = 16 output columns x 32 rows; the k range is split over the four waves
+//   (each streams a quarter of the 16 weight rows straight into MFMA operand registers: lane (n = lane & 15, k group = lane >> 4)
+//   holds W[n][32 s + 8 g .. + 7] as one 16-byte load; the activations' fragments come the same way, L2-resident), partial
+//   accumulators meet in LDS and are summed in wave order (bit-reproducible).  v_mfma_f32_16x16x32 with the WEIGHT as the first
+//   operand: a lane ends up with 4 consecutive output columns of one row -- the same orientation as gemm256.hip, so the epilogues
+//   (bias, Q scale, V^T scatter, LayerScale + residual, GELU) are the same arithmetic in the same order.
+#include "mhmr_common.h"
+#include "mhmr_internal.h"
+
+namespace {
+
+struct ClsArgs {
+    const void* A; long long a_stride;      // activation row b at A + b * a_stride (elements); k contiguous
+    const void* W; int ldw;                 // [N][ldw] weight rows (k contiguous)
+    int B, N, K, a_k;                       // K = total k (2 * a_k with a low-half weight pass: A's k index wraps at a_k), K % 128 == 0
+    const float* bias; const float* gamma;
+    void* out; long long o_stride;          // output row b at out + b * o_stride (elements of the output type)
+    int n_base, C;                          // CLS_QKV: global column of local column 0; embed dim (column regions Q | K | V)
+    void* vt; int H, Tp, vcol;              // CLS_QKV: V^T [B][H][64][Tp], the (already key-permuted) column of the class token
+};
+
+enum { CLS_QKV = 0, CLS_RESID = 1, CLS_GELU = 2 };
+
+template <int DT, int EPI>
+__global__ __launch_bounds__(256) void cls_linear_kernel(const ClsArgs a) {
+    typedef typename Op<DT>::T T;
+    typedef typename Op<DT>::V8 V8;
+    typedef typename Op<DT>::V4 V4;
+    __shared__ f32x4 red[3][2][64];                       // partial accumulators of waves 1..3
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g4 = lane >> 4, l15 = lane & 15;
+    const int n0 = blockIdx.x * 16, rb = blockIdx.y * 32;
+    // rows past B read row B - 1 (their results are dropped)
+    const int r0 = min(rb + l15, a.B - 1), r1 = min(rb + 16 + l15, a.B - 1);
+    const T* wp = (const T*)a.W + (size_t)(n0 + l15) * a.ldw + 8 * g4;
+    const T* a0p = (const T*)a.A + (size_t)r0 * a.a_stride + 8 * g4;
+    const T* a1p = (const T*)a.A + (size_t)r1 * a.a_stride + 8 * g4;
+    const int kq = a.K >> 2, k0 = w * kq;
+    const int awrap = a.a_k > 0 ? a.a_k : a.K;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int kk = k0; kk < k0 + kq; kk += 32) {
+        const int ka = kk >= awrap ? kk - awrap : kk;
+        const V8 wf = *(const V8*)(wp + kk);
+        const V8 x0 = *(const V8*)(a0p + ka);
+        const V8 x1 = *(const V8*)(a1p + ka);
+        acc0 = Op<DT>::mfma16(wf, x0, acc0);
+        acc1 = Op<DT>::mfma16(wf, x1, acc1);
+    }
+    if (w > 0) { red[w - 1][0][lane] = acc0; red[w - 1][1][lane] = acc1; }
+    __syncthreads();
+    if (w > 0) return;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { acc0 += red[i][0][lane]; acc1 += red[i][1][lane]; }      // wave order: bit-reproducible
+    // lane holds output columns n0 + 4 g4 + 0..3 of rows rb + l15 (acc0) and rb + 16 + l15 (acc1)
+    const int nl = n0 + 4 * g4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bv = *(const f32x4*)(a.bias + nl);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int m = rb + 16 * half + l15;
+        if (m >= a.B) continue;
+        const f32x4 v = (half ? acc1 : acc0) + bv;
+        if constexpr (EPI == CLS_RESID) {
+            float* op = (float*)a.out + (size_t)m * a.o_stride + nl;
+            const f32x4 gm = *(const f32x4*)(a.gamma + nl);
+            *(f32x4*)op = *(const f32x4*)op + gm * v;
+        } else if constexpr (EPI == CLS_GELU) {
+            V4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (T)gelu_fast(v[e]);
+            *(V4*)((T*)a.out + (size_t)m * a.o_stride + nl) = o;
+        } else {
+            const int ng = a.n_base + nl;                 // the 16 columns of a workgroup lie in one of the regions Q | K | V
+            if (ng < 2 * a.C) {
+                const float sc = ng < a.C ? MHMR_ATTN_QSCALE : 1.f;
+                V4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (T)(v[e] * sc);
+                *(V4*)((T*)a.out + (size_t)m * a.o_stride + ng) = o;
+            } else {
+                const int c = ng - 2 * a.C, h = c >> 6, d = c & 63;
+                T* vp = (T*)a.vt + ((size_t)(m * a.H + h) * 64 + d) * a.Tp + a.vcol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vp[(size_t)e * a.Tp] = (T)v[e];
+            }
+        }
+    }
+}
+
+template <int DT>
+int launch_cls(const ClsArgs& a, int epi, hipStream_t s) {
+    const dim3 grid(a.N / 16, (a.B + 31) / 32);
+    switch (epi) {
+        case CLS_QKV: hipLaunchKernelGGL((cls_linear_kernel<DT, CLS_QKV>), grid, dim3(256), 0, s, a); break;
+        case CLS_RESID: hipLaunchKernelGGL((cls_linear_kernel<DT, CLS_RESID>), grid, dim3(256), 0, s, a); break;
+        case CLS_GELU: hipLaunchKernelGGL((cls_linear_kernel<DT, CLS_GELU>), grid, dim3(256), 0, s, a); break;
+        default: return MHMR_ERR_BAD_ARG;
+    }
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+// epi: 0 = Q | K | V projection of the class rows (Q pre-scaled, V scattered into column `vcol` of V^T), 1 = out32 += gamma * (acc + bias),
+// 2 = out16 = gelu(acc + bias)
+int mhmr_launch_cls_linear(const void* A, long long a_stride, const void* W, int ldw, int B, int N, int K, int a_k, const float* bias,
+                           const float* gamma, void* out, long long o_stride, int n_base, int C, void* vt, int H, int Tp, int vcol, int epi,
+                           int dtype, hipStream_t s) {
+    if (B <= 0 || N <= 0 || N % 16 || K <= 0 || K % 128 || ldw < K || (a_k > 0 && K != 2 * a_k) || a_stride % 8 || ldw % 8) return MHMR_ERR_BAD_SHAPE;
+    if (epi == CLS_RESID && !gamma) return MHMR_ERR_BAD_ARG;
+    if (epi == CLS_QKV && (C % 64 || n_base % 16 || !vt || Tp <= vcol)) return MHMR_ERR_BAD_SHAPE;
+    const ClsArgs a{A, a_stride, W, ldw, B, N, K, a_k, bias, gamma, out, o_stride, n_base, C, vt, H, Tp, vcol};
+    return dtype == MHMR_DT_F16 ? launch_cls<MHMR_DT_F16>(a, epi, s) : launch_cls<MHMR_DT_BF16>(a, epi, s);
+}

@@ -33,13 +33,15 @@ __global__ void im2col_kernel(const float* __restrict__ x, void* __restrict__ a_
     *(V8*)((T*)a_ + (size_t)m * Kp + c8 * 8) = v;
 }
 
-// resid[b*Tp + 0][:] = cls_token + pos[0];  resid[b*Tp + t][:] = 0 for t in [T, Tp)
+// Token rows of image b: patch n at row b*Tp + n (n < N = T - 1), the CLASS token LAST at row b*Tp + N, zero padding behind it.
+// (Attention is permutation-equivariant over tokens, so the order is free; with the patches first, the 256-row GEMM tiles of the
+// patch rows never straddle the class row and B * N rows are a whole number of tile rounds.)
+// resid[b*Tp + N][:] = cls_token + pos[0];  resid[b*Tp + t][:] = 0 for t in [T, Tp)
 __global__ void init_rows_kernel(float* __restrict__ resid, const float* __restrict__ cls_pos0, int B, int T, int Tp, int C) {
     const int rows_per_img = 1 + (Tp - T);
     const int r = blockIdx.x;  // 0 .. B*rows_per_img
     const int b = r / rows_per_img, i = r - b * rows_per_img;
-    const int t = i == 0 ? 0 : T + i - 1;
-    float* dst = resid + ((size_t)b * Tp + t) * C;
+    float* dst = resid + ((size_t)b * Tp + (T - 1) + i) * C;
     for (int c = threadIdx.x; c < C; c += blockDim.x) dst[c] = i == 0 ? cls_pos0[c] : 0.f;
 }
 
@@ -63,9 +65,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     size_t in_row = row, out_row = row;
-    if constexpr (FINAL) {  // row = b*Np + n  reads token n+1 of image b
+    if constexpr (FINAL) {  // row = b*Np + n  reads patch token n of image b (row b*Tp + n: the class token is last)
         const int b = row / Np, n = row - b * Np;
-        in_row = (size_t)b * Tp + 1 + n;
+        in_row = (size_t)b * Tp + n;
     }
     const float* ip = in + in_row * C;
     fv v[NP];

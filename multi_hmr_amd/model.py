@@ -239,6 +239,9 @@ class Model(nn.Module):
         self.precision = kwargs.get("precision", os.environ.get("MHMR_PRECISION", "f16"))
         if self.precision not in packing.OP_DTYPES:
             raise ValueError(f"precision must be one of {list(packing.OP_DTYPES)}")
+        # low-half weight passes of the V / output projections (vit.DEFAULT_WLO; "" = none): what puts every output within 1e-3
+        self.wlo = kwargs.get("wlo", os.environ.get("MHMR_WLO"))
+        vit.parse_wlo(vit.DEFAULT_WLO if self.wlo is None else self.wlo, 64)       # fail early on a malformed spec
         self.backbone = Dinov2Backbone(backbone, pretrained=pretrained_backbone, depth_override=kwargs.get("backbone_depth"))
         self.embed_dim, self.patch_size = self.backbone.embed_dim, self.backbone.patch_size
         assert self.img_size % self.patch_size == 0, "Invalid img size"
@@ -280,7 +283,7 @@ class Model(nn.Module):
 
     def _pack(self, device):
         self._ws.clear()
-        P = vit.pack_encoder(self.backbone.encoder, self.img_size, self.precision, device)
+        P = vit.pack_encoder(self.backbone.encoder, self.img_size, self.precision, device, self.wlo)
         dt_id, tdt = P["dt_id"], P["tdt"]
         C, G, N = P["C"], P["G"], P["N"]
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()

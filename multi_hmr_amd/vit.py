@@ -16,7 +16,34 @@ from .packing import roundup
 PATCH = 14
 
 
-def pack_encoder(enc, img_size: int, precision: str, device) -> dict:
+#: default low-half weight passes (tools/precision_study.py): which projections of which blocks also carry the low
+#: half of their weights.  "v+proj@0-11" = the V and the attention output projections of blocks 0..11.  "" = none.
+DEFAULT_WLO = "v+proj@0-11"
+
+
+def parse_wlo(spec: str, depth: int) -> dict:
+    """'v+proj@0-11,proj@12-15' -> {block index: {'v', 'proj'}}; block ranges are clipped to the encoder's depth."""
+    out = {}
+    for part in filter(None, (s.strip() for s in (spec or "").split(","))):
+        names, _, rng = part.partition("@")
+        lo, _, hi = (rng or f"0-{depth - 1}").partition("-")
+        names = set(names.split("+"))
+        if not names <= {"v", "proj"}:
+            raise ValueError(f"low-half weight passes exist for 'v' and 'proj', not {sorted(names)}")
+        for i in range(int(lo), min(int(hi or lo), depth - 1) + 1):
+            out.setdefault(i, set()).update(names)
+    return out
+
+
+def hi_lo(w: torch.Tensor, tdt) -> torch.Tensor:
+    """fp32 [N, K] -> 16-bit [N, 2K] = [W_hi | W_lo]: W_hi = round16(W), W_lo = round16(W - W_hi) (for f16 mostly subnormal: the
+    matrix pipe takes them at full precision, tests/test_gpu_kernels.py::test_gemm_low_half_weight_pass)."""
+    hi = w.to(tdt)
+    lo = (w - hi.float()).to(tdt)
+    return torch.cat([hi, lo], dim=1).contiguous()
+
+
+def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = None) -> dict:
     """DINOv2 encoder parameters (key names of torch.hub dinov2_vit*14) -> device tensors in the kernels' layouts.
 
     16-bit [N, K] linears (K contiguous = MFMA operand order), fp32 biases / LayerNorm / LayerScale, the pos-embed bicubically
@@ -41,8 +68,12 @@ def pack_encoder(enc, img_size: int, precision: str, device) -> dict:
     pw = torch.zeros(Cd, P["Kp"], dtype=torch.float32, device=device)
     pw[:, :588] = f32(enc.patch_embed.proj.weight).reshape(Cd, 588)
     blocks = (_lib.VitBlock * L)()
+    lo_passes = parse_wlo(DEFAULT_WLO if wlo is None else wlo, L)
+    P["wlo"] = {i: sorted(v) for i, v in lo_passes.items()}
     for i, b in enumerate(enc.blocks):
         blk = blocks[i]
+        blk.v_w2 = k(hi_lo(f32(b.attn.qkv.weight)[2 * Cd:], tdt)) if "v" in lo_passes.get(i, ()) else None
+        blk.proj_w2 = k(hi_lo(f32(b.attn.proj.weight), tdt)) if "proj" in lo_passes.get(i, ()) else None
         blk.ln1_w, blk.ln1_b = k(f32(b.norm1.weight)), k(f32(b.norm1.bias))
         blk.qkv_w, blk.qkv_b = k(op(b.attn.qkv.weight)), k(f32(b.attn.qkv.bias))
         blk.proj_w, blk.proj_b, blk.ls1 = k(op(b.attn.proj.weight)), k(f32(b.attn.proj.bias)), k(f32(b.ls1.gamma))

@@ -126,7 +126,7 @@ def test_gemm_epilogues(L, name, dt, tdt, tol, M, N, K):
 @pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
 def test_gemm_patch_and_vt_layouts(L, name, dt, tdt, tol):
     g = torch.Generator(device="cpu").manual_seed(7)
-    # patch epilogue: rows scattered to (b*Tp + 1 + n), + pos[1+n]; rows >= Mvalid dropped
+    # patch epilogue: rows scattered to (b*Tp + n) -- the class token is the LAST token row of an image --, + pos[1+n]; rows >= Mvalid dropped
     B, Np, Tp, N, K = 3, 100, 128, 128, 128
     M, Mvalid = 384, B * Np
     A = torch.randn(M, K, generator=g).to(dev()).to(tdt)
@@ -138,8 +138,8 @@ def test_gemm_patch_and_vt_layouts(L, name, dt, tdt, tol):
                              2, Mvalid, _lib.EPI_PATCH, dt, stream()), "gemm patch")
     ref = (A.float() @ W.float().T + bias)[:Mvalid].view(B, Np, N) + pos[1:]
     got = out.view(B, Tp, N)
-    assert maxrel(got[:, 1:1 + Np], ref) < 2e-5
-    assert torch.all(got[:, 0] == 7.0) and torch.all(got[:, 1 + Np:] == 7.0)       # untouched rows
+    assert maxrel(got[:, :Np], ref) < 2e-5
+    assert torch.all(got[:, Np:] == 7.0)                                            # untouched rows (class slot + padding)
     # V^T epilogue
     B, H, Tp = 2, 2, 256
     M, N, K = B * Tp, H * 64, 64
@@ -164,8 +164,8 @@ def test_gemm_patch_and_vt_layouts(L, name, dt, tdt, tol):
                              2, Mvalid, _lib.EPI_PATCH, dt, stream()), "gemm patch 256")
     ref = (A.float() @ W.float().T + bias)[:Mvalid].view(B, Np, N) + pos[1:]
     got = out.view(B, Tp, N)
-    assert maxrel(got[:, 1:1 + Np], ref) < 2e-5
-    assert torch.all(got[:, 0] == 7.0) and torch.all(got[:, 1 + Np:] == 7.0)
+    assert maxrel(got[:, :Np], ref) < 2e-5
+    assert torch.all(got[:, Np:] == 7.0)
     B, H, Tp = 2, 4, 384
     M, N, K = B * Tp, H * 64, 128
     A = torch.randn(M, K, generator=g).to(dev()).to(tdt)
@@ -177,6 +177,119 @@ def test_gemm_patch_and_vt_layouts(L, name, dt, tdt, tol):
     ref = (A.float() @ W.float().T + bias).view(B, Tp, H, 64).permute(0, 2, 3, 1)
     perm = swap23(torch.arange(Tp, device=dev()))
     assert maxrel(vt.float()[..., perm], ref) < tol
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("N,K", [(256, 256), (512, 128), (384, 192)])            # 256x256 kernel twice, 128x128 kernel
+def test_gemm_token_row_map(L, name, dt, tdt, tol, N, K):
+    """mhmr_gemm16_ex with img_rows / img_stride: the GEMM covers rows b * Tp + [0, Nimg) of every image and must neither read nor
+    write the class / padding rows behind them (ViT block linears over the patch rows only)."""
+    B, Nimg, Tp, H = 3, 256, 320, N // 64
+    g = torch.Generator(device="cpu").manual_seed(N + K)
+    A = torch.randn(B * Tp, K, generator=g).to(dev()).to(tdt)
+    A.view(B, Tp, K)[:, Nimg:] = float("nan")                                    # a read of a skipped row poisons the result
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev()).to(tdt)
+    bias, gamma = torch.randn(N, generator=g).to(dev()), torch.randn(N, generator=g).to(dev())
+    ref = A.view(B, Tp, K)[:, :Nimg].float() @ W.float().T + bias                # [B, Nimg, N]
+    call = lambda out, ldo, epi, gm=None: _lib.check(L.mhmr_gemm16_ex(A.data_ptr(), K, W.data_ptr(), K, B * Nimg, N, K, bias.data_ptr(), gm,
+                                                                      out.data_ptr(), ldo, None, 0, Tp, H, B * Nimg, epi, dt, Nimg, Tp, 0,
+                                                                      stream()), "gemm_ex")
+    out = torch.full((B, Tp, N), 7.0, dtype=tdt, device=dev())
+    call(out, N, _lib.EPI_OP16)
+    assert maxrel(out[:, :Nimg].float(), ref) < tol and torch.all(out[:, Nimg:] == 7.0)
+    call(out, N, _lib.EPI_OP16_GELU)
+    assert maxrel(out[:, :Nimg].float(), torch.nn.functional.gelu(ref)) < tol and torch.all(out[:, Nimg:] == 7.0)
+    res = torch.randn(B, Tp, N, generator=g).to(dev())
+    o32 = res.clone()
+    call(o32, N, _lib.EPI_RESID, gamma.data_ptr())
+    assert maxrel(o32[:, :Nimg], res[:, :Nimg] + gamma * ref) < 2e-5 and torch.equal(o32[:, Nimg:], res[:, Nimg:])
+    vt = torch.full((B, H, 64, Tp), 7.0, dtype=tdt, device=dev())
+    call(vt, 0, _lib.EPI_VT)
+    perm = swap23(torch.arange(Nimg, device=dev()))
+    assert maxrel(vt.float()[..., perm], ref.view(B, Nimg, H, 64).permute(0, 2, 3, 1)) < tol
+    assert torch.all(vt[..., Nimg:] == 7.0)
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (128, 128, 64), (512, 256, 1024)])
+def test_gemm_low_half_weight_pass(L, name, dt, tdt, tol, M, N, K):
+    """W = [W_hi | W_lo] along k with the activation's k index wrapping (a_k): one accumulator chain computes A . (W_hi + W_lo)^T.  The
+    low halves of f16 weights are mostly SUBNORMAL f16 numbers -- the matrix pipe must take them at full precision -- so the result
+    is compared with the fp32 weights: the residual weight error drops from 2^-11 to ~2^-19 relative."""
+    from multi_hmr_amd import vit
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).to(dev()).to(tdt)
+    W32 = (torch.randn(N, K, generator=g) * 0.02).to(dev())
+    W2 = vit.hi_lo(W32, tdt)                                                     # [N, 2K]
+    if name == "f16":
+        lo = W2[:, K:].float().abs()
+        assert float((lo[lo > 0] < 2.0 ** -14).float().mean()) > 0.9             # the low halves really are subnormal
+    bias = torch.randn(N, generator=g).to(dev())
+    exact = A.double() @ W32.double().T + bias.double()
+    o32 = torch.zeros(M, N, device=dev())
+    _lib.check(L.mhmr_gemm16_ex(A.data_ptr(), K, W2.data_ptr(), 2 * K, M, N, 2 * K, bias.data_ptr(), None, o32.data_ptr(), N, None, 0, 128,
+                                1, M, _lib.EPI_F32, dt, 0, 0, K, stream()), "gemm lo")
+    one = torch.zeros(M, N, device=dev())
+    _lib.check(L.mhmr_gemm16(A.data_ptr(), K, W2[:, :K].contiguous().data_ptr(), K, M, N, K, bias.data_ptr(), None, one.data_ptr(), N, None, 0,
+                             128, 1, M, _lib.EPI_F32, dt, stream()), "gemm hi")
+    e2, e1 = rel(o32, exact), rel(one, exact)
+    assert e1 > (1e-4 if name == "f16" else 1e-3)                                # a single pass carries the weight rounding ...
+    assert e2 < e1 / (30 if name == "f16" else 30), (e1, e2)                     # ... the low-half pass removes it
+    # V^T form (the activation is the FIRST operand there)
+    if M % 128 == 0 and N % 64 == 0:
+        B, H, Tp = 1, N // 64, M
+        vt = torch.zeros(B, H, 64, Tp, dtype=tdt, device=dev())
+        _lib.check(L.mhmr_gemm16_ex(A.data_ptr(), K, W2.data_ptr(), 2 * K, M, N, 2 * K, bias.data_ptr(), None, vt.data_ptr(), 0, None, 0, Tp,
+                                    H, M, _lib.EPI_VT, dt, 0, 0, K, stream()), "gemm lo vt")
+        perm = swap23(torch.arange(Tp, device=dev()))
+        assert maxrel(vt.float()[..., perm], exact.float().view(B, Tp, H, 64).permute(0, 2, 3, 1)) < tol
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("B", [3, 32, 40])
+def test_cls_linear(L, name, dt, tdt, tol, B):
+    """The class-token rows of the block linears (csrc/vit_cls.hip): B rows Tp apart, the three epilogues, with and without the
+    low-half weight pass, against torch on the same (rounded) operands."""
+    from multi_hmr_amd import vit
+    C, H, Tp, Ncls = 256, 4, 192, 130
+    g = torch.Generator(device="cpu").manual_seed(B)
+    xn = torch.randn(B * Tp, C, generator=g).to(dev()).to(tdt)
+    rows = xn.view(B, Tp, C)[:, Ncls].float()                                   # [B, C]
+    Wqkv = (torch.randn(3 * C, C, generator=g) / math.sqrt(C)).to(dev()).to(tdt)
+    bqkv = torch.randn(3 * C, generator=g).to(dev())
+    qk = torch.full((B * Tp, 2 * C), 7.0, dtype=tdt, device=dev())
+    vt = torch.full((B, H, 64, Tp), 7.0, dtype=tdt, device=dev())
+    vcol = int(swap23(torch.tensor(Ncls)))
+    esz = 2
+    _lib.check(L.mhmr_cls_linear16(xn.data_ptr() + Ncls * C * esz, Tp * C, Wqkv.data_ptr(), C, B, 3 * C, C, 0, bqkv.data_ptr(), None,
+                                   qk.data_ptr() + Ncls * 2 * C * esz, Tp * 2 * C, 0, C, vt.data_ptr(), H, Tp, vcol, 0, dt, stream()), "cls qkv")
+    ref = rows @ Wqkv.float().T + bqkv
+    got = qk.view(B, Tp, 2 * C)
+    assert maxrel(got[:, Ncls, :C].float(), ref[:, :C] * _lib.ATTN_QSCALE) < tol
+    assert maxrel(got[:, Ncls, C:].float(), ref[:, C:2 * C]) < tol
+    assert maxrel(vt[..., vcol].float(), ref[:, 2 * C:].view(B, H, 64)) < tol
+    assert torch.all(got[:, :Ncls] == 7.0) and torch.all(got[:, Ncls + 1:] == 7.0)
+    assert torch.all(vt[..., :vcol] == 7.0) and torch.all(vt[..., vcol + 1:] == 7.0)
+    # residual epilogue with the low-half pass (K = 2 a_k)
+    W32 = (torch.randn(C, C, generator=g) * 0.05).to(dev())
+    W2 = vit.hi_lo(W32, tdt)
+    bias, gamma = torch.randn(C, generator=g).to(dev()), torch.randn(C, generator=g).to(dev())
+    res = torch.randn(B * Tp, C, generator=g).to(dev())
+    o32 = res.clone()
+    _lib.check(L.mhmr_cls_linear16(xn.data_ptr() + Ncls * C * esz, Tp * C, W2.data_ptr(), 2 * C, B, C, 2 * C, C, bias.data_ptr(), gamma.data_ptr(),
+                                   o32.data_ptr() + Ncls * C * 4, Tp * C, 0, C, None, H, Tp, 0, 1, dt, stream()), "cls resid")
+    exact = res.view(B, Tp, C)[:, Ncls] + gamma * (rows @ W32.T + bias)
+    assert maxrel(o32.view(B, Tp, C)[:, Ncls], exact) < 3e-5 if name == "f16" else 3e-4
+    keep = torch.ones(B, Tp, dtype=torch.bool, device=dev())
+    keep[:, Ncls] = False
+    assert torch.equal(o32.view(B, Tp, C)[keep], res.view(B, Tp, C)[keep])
+    # GELU epilogue
+    W1 = (torch.randn(2 * C, C, generator=g) / math.sqrt(C)).to(dev()).to(tdt)
+    b1 = torch.randn(2 * C, generator=g).to(dev())
+    hid = torch.full((B * Tp, 2 * C), 7.0, dtype=tdt, device=dev())
+    _lib.check(L.mhmr_cls_linear16(xn.data_ptr() + Ncls * C * esz, Tp * C, W1.data_ptr(), C, B, 2 * C, C, 0, b1.data_ptr(), None,
+                                   hid.data_ptr() + Ncls * 2 * C * esz, Tp * 2 * C, 0, C, None, H, Tp, 0, 2, dt, stream()), "cls gelu")
+    assert maxrel(hid.view(B, Tp, 2 * C)[:, Ncls].float(), torch.nn.functional.gelu(rows @ W1.float().T + b1)) < tol
 
 
 # ------------------------------------------------------------------------------------------------------ attention
@@ -200,7 +313,7 @@ def _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=None, variant=0):
     else:
         flags = torch.full((L.mhmr_attention_flag_count(B, Tp, H),), 7, dtype=torch.int32, device=dev())   # (the call writes every entry)
         _lib.check(L.mhmr_attention16_ex(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), B, T, Tp, C, H, dt, thr, variant,
-                                         flags.data_ptr() if variant == 0 else None, stream()), "attention_ex")
+                                         flags.data_ptr() if variant in (0, 4, 5) else None, stream()), "attention_ex")
         _attn_run.last_flags = flags
     return out.view(B, Tp, C)
 
@@ -214,19 +327,22 @@ def _attn_ref(q, k, v, T, rows=None):
 
 
 @pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
-@pytest.mark.parametrize("B,H,T,pad", [(2, 3, 200, 128), (1, 2, 256, 128), (1, 1, 65, 128), (2, 6, 257, 128), (2, 6, 257, 64), (3, 2, 130, 64)])
-def test_attention(L, name, dt, tdt, tol, B, H, T, pad):
+@pytest.mark.parametrize("variant", [None, 0, 4, 5])     # None = mhmr_attention16; 0 = 32 queries per wave; 4 / 5 = 64 queries per wave
+@pytest.mark.parametrize("B,H,T,pad", [(2, 3, 200, 128), (1, 2, 256, 128), (1, 1, 65, 128), (2, 6, 257, 128), (2, 6, 257, 64), (3, 2, 130, 64),
+                                       (1, 2, 577, 64), (2, 1, 40, 64)])
+def test_attention(L, name, dt, tdt, tol, B, H, T, pad, variant):
     q, k, v, C, Tp = _attn_inputs(B, H, T, tdt, T, pad=pad)          # pad = 64: rows per image not a multiple of the 128-query workgroup
     k[0, min(T - 1, 70), 0] *= 6.0          # a spiked key moves the row maximum late in the loop
-    got = _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt)[:, :T].double()
+    got = _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=None if variant is None else 15.0, variant=variant or 0)[:, :T].double()
     err = float((got - _attn_ref(q, k, v, T)).abs().max())
     assert err < (4e-3 if name == "f16" else 3e-2), err
     assert torch.isfinite(got).all()
 
 
 @pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("variant", [0, 4, 5])
 @pytest.mark.parametrize("target", [10.0, 40.0])
-def test_attention_last_key_rank_one_update(L, name, dt, tdt, tol, target):
+def test_attention_last_key_rank_one_update(L, name, dt, tdt, tol, target, variant):
     """T = 64 n + 1: the default kernel form folds the lone key of the last tile in as a rank-1 update.  A last key that dominates
     a query's softmax (score +10 above the level: stays in range) or leaves the 16-bit range (+40: the workgroup is flagged and
     recomputed by the textbook form) must both match fp64."""
@@ -237,21 +353,22 @@ def test_attention_last_key_rank_one_update(L, name, dt, tdt, tol, target):
         d = q.float()[bb, row, hh]
         kk[bb, T - 1, hh] = d / d.norm() ** 2 * target
     k = kk.to(tdt)
-    got = _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=15.0, variant=0)[:, :T].double()
+    got = _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=15.0, variant=variant)[:, :T].double()
     flagged = int(_attn_run.last_flags.sum().item())
     assert (flagged > 0) == (target > 15.0), flagged
     err = float((got - _attn_ref(q, k, v, T)).abs().max())
     assert err < (4e-3 if name == "f16" else 3e-2), err
 
 
+@pytest.mark.parametrize("variant", [0, 4])
 @pytest.mark.parametrize("pad", [128, 64])               # rows per image: 2432 / 4224 / 8576 or 2368 / 4160 / 8512 (vit.padded_tokens)
 @pytest.mark.parametrize("T", [2305, 4097, 8465])        # 672^2, 896^2, 1288^2: 37 / 65 / 133 key tiles, the last one masked
-def test_attention_full_length_against_fp64(L, T, pad):
+def test_attention_full_length_against_fp64(L, T, pad, variant):
     """BASELINE sequence lengths, f16 operands, against fp64 on sampled query rows (first / last rows, tile and workgroup
     boundaries, random rows); absolute error of an output that is an average of N(0,1) values."""
     B, H = 2, 2
     q, k, v, C, Tp = _attn_inputs(B, H, T, torch.float16, T, pad=pad)
-    got = _attn_run(L, q, k, v, B, H, T, C, Tp, _lib.DT_F16, torch.float16)
+    got = _attn_run(L, q, k, v, B, H, T, C, Tp, _lib.DT_F16, torch.float16, thr=15.0, variant=variant)
     g = torch.Generator(device="cpu").manual_seed(1)
     rows = torch.cat([torch.tensor([0, 1, 31, 32, 63, 64, 127, 128, T - 130, T - 129, T - 65, T - 64, T - 2, T - 1]),
                       torch.randint(0, T, (50,), generator=g)]).unique().to(dev())
@@ -291,9 +408,13 @@ def test_attention_reference_level_branches_are_exact(L, name, dt, tdt, tol):
         assert err < bound, (lim, err)
     for lim in (15.0, 6.0):      # same function, different rounding order: at most one output ulp apart (|O| <= ~4)
         assert float((outs[lim] - outs[0.0]).abs().max()) <= (2.0 ** -8 if name == "f16" else 2.0 ** -5), lim
-    for variant in (1, 2):       # the A/B forms compute the same function
+    for variant in (1, 2, 4, 5):       # the A/B forms compute the same function
         got = _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=15.0, variant=variant)[:, :T].double()
         assert float((got - ref).abs().max()) < bound, variant
+    for lim in (0.0, 6.0):             # 64 queries per wave: the flag path (workgroup numbering of the fallback kernel) at low limits
+        got = _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=lim, variant=4)[:, :T].double()
+        assert float((got - ref).abs().max()) < bound, ("v4", lim)
+        assert float((got - outs[0.0]).abs().max()) <= (2.0 ** -8 if name == "f16" else 2.0 ** -5), ("v4", lim)
 
 
 # ------------------------------------------------------------------------------------------------------ norms, patchify
