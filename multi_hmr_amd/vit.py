@@ -87,12 +87,22 @@ def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = N
     return P
 
 
+def row_map(P: dict, B: int) -> bool:
+    """Mirror of the rule in csrc/capi.hip (mhmr_vit_forward): the five big GEMMs of a block run over the B * N patch rows only (the
+    class rows through csrc/vit_cls.hip) when an image's patch rows are whole 256-row tiles of the 256x256 kernel."""
+    import os
+    T = P["T"]
+    return (os.environ.get("MHMR_ROWMAP", "1") != "0" and P["C"] % 256 == 0 and (T - 1) % 256 == 0 and
+            B * roundup(T, 64) * P["C"] * 4 < 2 ** 32)
+
+
 def padded_tokens(P: dict, B: int) -> int:
-    """Rows per image in the token-major workspaces.  A multiple of 64 (the attention key tile, the V^T row granularity) when that
-    still leaves every linear of the encoder on the 256x256 kernel (embed_dim and B * Tp multiples of 256); otherwise a multiple of
-    128, the row tile of the 128x128 kernel.  896^2: 4160 instead of 4224 rows per image, 1.5 % fewer GEMM / LayerNorm rows."""
+    """Rows per image in the token-major workspaces (patch tokens, the class token, zero padding).  A multiple of 64 (the attention key
+    tile, the V^T row granularity) when every linear of the encoder stays on the 256x256 kernel -- the GEMMs cover the patch rows only
+    (row_map), or embed_dim and B * Tp are multiples of 256; otherwise a multiple of 128, the row tile of the 128x128 kernel.
+    896^2: 4160 instead of 4224 rows per image."""
     t64, t128 = roundup(P["T"], 64), roundup(P["T"], 128)
-    return t64 if (P["C"] % 256 == 0 and (B * t64) % 256 == 0) else t128
+    return t64 if (row_map(P, B) or (P["C"] % 256 == 0 and (B * t64) % 256 == 0)) else t128
 
 
 class WorkspaceCache:

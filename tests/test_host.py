@@ -120,13 +120,19 @@ def test_pack_smplx_rejects_a_basis_outside_the_f16_pair_range(smplx_data):
     packing.pack_smplx(smplx_data, 10, "cpu")
 
 
-def test_token_rows_per_image_rule():
-    """vit.padded_tokens: 64-row padding only while every encoder linear stays on the 256x256 kernel (C and B * Tp multiples of
-    256); otherwise the 128-row tile of the 128x128 kernel."""
+def test_token_rows_per_image_rule(monkeypatch):
+    """vit.padded_tokens: 64-row padding while every encoder linear stays on the 256x256 kernel -- the block GEMMs cover the patch rows
+    only (N % 256 == 0: 672^2, 896^2), or C and B * Tp are multiples of 256; otherwise the 128-row tile of the 128x128 kernel."""
     from multi_hmr_amd import vit
     L = {"C": 1024, "T": 4097}
-    assert vit.padded_tokens(L, 32) == 4160 and vit.padded_tokens(L, 4) == 4160 and vit.padded_tokens(L, 1) == 4224 and vit.padded_tokens(L, 6) == 4224
-    assert vit.padded_tokens({"C": 1024, "T": 2305}, 32) == 2368 and vit.padded_tokens({"C": 1024, "T": 8465}, 8) == 8512
+    assert all(vit.padded_tokens(L, b) == 4160 for b in (32, 4, 1, 6)) and vit.row_map(L, 32)
+    assert vit.padded_tokens({"C": 1024, "T": 2305}, 32) == 2368 and vit.padded_tokens({"C": 1024, "T": 2305}, 1) == 2368
+    assert vit.padded_tokens({"C": 1024, "T": 8465}, 8) == 8512 and not vit.row_map({"C": 1024, "T": 8465}, 8)      # 1288^2: N = 8464
+    assert vit.padded_tokens({"C": 1024, "T": 8465}, 1) == 8576
     assert vit.padded_tokens({"C": 384, "T": 2305}, 16) == 2432           # ViT-S: proj / fc2 / V run on the 128x128 kernel
     assert vit.padded_tokens({"C": 768, "T": 2305}, 16) == 2368           # ViT-B: 256-multiples throughout
-    assert vit.padded_tokens({"C": 1024, "T": 257}, 8) == 320 and vit.padded_tokens({"C": 1024, "T": 257}, 2) == 384
+    assert vit.padded_tokens({"C": 1024, "T": 257}, 8) == 320 and vit.padded_tokens({"C": 1024, "T": 257}, 2) == 320 and vit.row_map({"C": 1024, "T": 257}, 2)
+    assert not vit.row_map(L, 512)                                        # 32-bit residual offsets of the 256x256 kernel
+    monkeypatch.setenv("MHMR_ROWMAP", "0")                                # the A/B switch of csrc/capi.hip
+    assert vit.padded_tokens(L, 32) == 4160 and vit.padded_tokens(L, 1) == 4224 and vit.padded_tokens(L, 6) == 4224
+    assert vit.padded_tokens({"C": 1024, "T": 257}, 2) == 384

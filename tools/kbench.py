@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--tp", type=int, default=0, help="override the padded token count per image (GEMM rows = batch * tp)")
     ap.add_argument("--variants", default="0", help="attention kernel forms to time (comma separated, csrc/attention.hip)")
     ap.add_argument("--thr", type=float, default=15.0, help="attention reference-level limit (log2)")
+    ap.add_argument("--rows", default="all,map", help="GEMM row modes to time: all (B * Tp rows) and / or map (the B * N patch rows)")
     a = ap.parse_args()
     L = _lib.lib()
     dt, tdt = (_lib.DT_F16, torch.float16) if a.dtype == "f16" else (_lib.DT_BF16, torch.bfloat16)
@@ -44,20 +45,32 @@ def main():
     B, C, H = a.batch, 1024, 16
     G = a.img // 14
     T = G * G + 1
-    Tp = a.tp if a.tp else (T + 127) // 128 * 128
+    Tp = a.tp if a.tp else (T + 63) // 64 * 64
     M = B * Tp
     rnd = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(tdt)
     if a.only in ("", "gemm"):
-        shapes = [("qk   (EPI_OP16)", 2 * C, C, _lib.EPI_OP16), ("qk   (EPI_OP16_QK)", 2 * C, C, _lib.EPI_OP16_QK), ("v    (EPI_VT)", C, C, _lib.EPI_VT), ("proj (EPI_RESID)", C, C, _lib.EPI_RESID),
-                  ("fc1  (EPI_GELU)", 4 * C, C, _lib.EPI_OP16_GELU), ("fc2  (EPI_RESID)", C, 4 * C, _lib.EPI_RESID)]
-        for name, N, K, epi in shapes:
-            A, W = rnd(M, K), (torch.randn(N, K, device=dev) / math.sqrt(K)).to(tdt)
-            bias, gamma = torch.randn(N, device=dev), torch.randn(N, device=dev)
-            out = torch.zeros(M * N, dtype=torch.float32 if epi == _lib.EPI_RESID else tdt, device=dev)
-            fn = lambda: _lib.check(L.mhmr_gemm16(A.data_ptr(), K, W.data_ptr(), K, M, N, K, bias.data_ptr(), gamma.data_ptr(), out.data_ptr(),
-                                                  N, None, 0, Tp, H, M, epi, dt, st), "gemm")
-            ms = timeit(fn, a.iters)
-            print(f"gemm {name:18s} M={M} N={N} K={K}: {ms:8.4f} ms  {2.0 * B * T * N * K / ms / 1e9:8.1f} TFLOP/s (alg)  {2.0 * M * N * K / ms / 1e9:8.1f} (padded)")
+        N_img = T - 1
+        shapes = [("qk   (EPI_OP16_QK)", 2 * C, C, _lib.EPI_OP16_QK, 0), ("v    (EPI_VT)", C, C, _lib.EPI_VT, 0), ("v+lo (EPI_VT)", C, C, _lib.EPI_VT, 1),
+                  ("proj (EPI_RESID)", C, C, _lib.EPI_RESID, 0), ("proj+lo (EPI_RESID)", C, C, _lib.EPI_RESID, 1),
+                  ("fc1  (EPI_GELU)", 4 * C, C, _lib.EPI_OP16_GELU, 0), ("fc2  (EPI_RESID)", C, 4 * C, _lib.EPI_RESID, 0)]
+        # rows: "all" = one GEMM over all B * Tp rows (class + padding rows included), "map" = the B * N patch rows only (token-row map)
+        modes = [m for m in a.rows.split(",") if m]
+        for name, N, K, epi, lo in shapes:
+            for mode in modes:
+                if mode == "map" and N_img % 256:
+                    continue
+                Mg, ir, istr = (B * N_img, N_img, Tp) if mode == "map" else (M, 0, 0)
+                Kw = 2 * K if lo else K
+                A, W = rnd(M, K), (torch.randn(N, Kw, device=dev) / math.sqrt(K) * (1.0 if not lo else 1.0)).to(tdt)
+                if lo:
+                    W[:, K:] = (W[:, K:].float() * 2.0 ** -11).to(tdt)
+                bias, gamma = torch.randn(N, device=dev), torch.randn(N, device=dev)
+                out = torch.zeros(M * N, dtype=torch.float32 if epi == _lib.EPI_RESID else tdt, device=dev)
+                fn = lambda: _lib.check(L.mhmr_gemm16_ex(A.data_ptr(), K, W.data_ptr(), Kw, Mg, N, Kw, bias.data_ptr(), gamma.data_ptr(), out.data_ptr(),
+                                                         N, None, 0, Tp, H, Mg, epi, dt, ir, istr, K if lo else 0, st), "gemm")
+                ms = timeit(fn, a.iters)
+                print(f"gemm {name:20s} rows={mode:3s} M={Mg} N={N} K={Kw}: {ms:8.4f} ms  {2.0 * B * T * N * K / ms / 1e9:8.1f} TFLOP/s (alg, single pass)", flush=True)
+                del A, W, out
     if a.only in ("", "attn"):
         qk, vt, out = rnd(M, 2 * C), rnd(B * H * 64, Tp), torch.zeros(M, C, dtype=tdt, device=dev)
         qk[:, :C] = (qk[:, :C].float() * _lib.ATTN_QSCALE).to(tdt)          # the Q half arrives pre-scaled (MHMR_EPI_OP16_QK)
@@ -65,7 +78,7 @@ def main():
         for rnd_ in range(2):                                                # two interleaved rounds: within-process A/B
             for var in [int(v) for v in a.variants.split(",")]:
                 fn = lambda: _lib.check(L.mhmr_attention16_ex(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), B, T, Tp, C, H, dt, a.thr,
-                                                              var, flags.data_ptr() if var == 0 else None, st), "attn")
+                                                              var, flags.data_ptr() if var in (0, 4, 5) else None, st), "attn")
                 ms = timeit(fn, a.iters)
                 print(f"attention variant {var} B={B} H={H} T={T} {a.dtype}: {ms:8.4f} ms  {4.0 * B * H * T * T * 64 / ms / 1e9:8.1f} TFLOP/s (alg)", flush=True)
     if a.only in ("", "ln"):
