@@ -269,7 +269,8 @@ int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s) {
             g2.stagger_ticks = (int)((g.K / 64 * 1.4 + 18.0) * 25.0 * (st ? atoi(st) : 100) / 100.0);
         static const char* cg = getenv("MHMR_COLGROUP");
         g2.colgroup = cg ? atoi(cg) : 1;
-        if (g.img_rows > 0) g2.img_magic = (unsigned)((1ull << 32) / (unsigned)(g.img_rows >> 8)) + 1u;     // exact while tm * tiles_per_image < 2^32
+        // image of a row tile = umulhi(tm, magic), exact while tm * tiles_per_image < 2^32; one tile per image: magic 0 = identity
+        if (g.img_rows > 256) g2.img_magic = (unsigned)((1ull << 32) / (unsigned)(g.img_rows >> 8)) + 1u;
         rc = mhmr_launch_gemm256(g2, dtype, s);
     }
     else rc = dtype == MHMR_DT_F16 ? launch_dt<MHMR_DT_F16>(g, s) : launch_dt<MHMR_DT_BF16>(g, s);

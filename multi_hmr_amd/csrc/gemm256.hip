@@ -87,7 +87,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         bimg = 0;
         ar = tm * 256;
         if (g.img_rows > 0) {
-            bimg = (int)__umulhi((unsigned)tm, g.img_magic);
+            bimg = g.img_magic ? (int)__umulhi((unsigned)tm, g.img_magic) : tm;        // (magic 0: one tile per image)
             ar = bimg * g.img_stride + (tm - bimg * (g.img_rows >> 8)) * 256;
         }
         pb = Pm + (size_t)(ROWMAJOR ? p0 : ar) * (size_t)ldp;

@@ -30,7 +30,7 @@ struct GemmArgs {
     // b * img_stride + n.  The big linears then run over the B * N patch rows only (exactly 8 / 16 / 32 rounds of 256 tiles at
     // 896^2 x 32) and skip the class + padding rows of every image (vit_cls.hip computes the class rows).  0 = rows are physical.
     int img_rows = 0, img_stride = 0;
-    unsigned img_magic = 0;  // floor(2^32 / (img_rows / 256)) + 1, set by mhmr_launch_gemm: image of row tile tm = umulhi(tm, img_magic)
+    unsigned img_magic = 0;  // floor(2^32 / (img_rows / 256)) + 1 (0 when img_rows == 256), set by mhmr_launch_gemm: image of row tile tm = umulhi(tm, img_magic)
     // Low-half weight pass: W = [W_hi | W_lo] along k (ldw >= K, K = 2 * a_k): k tiles >= a_k / 64 re-read the activation's k tiles
     // from the start, so acc = A . W_hi^T + A . W_lo^T in one accumulator chain.  0 = off.
     int a_k = 0;

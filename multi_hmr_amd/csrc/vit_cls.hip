@@ -29,7 +29,9 @@ struct ClsArgs {
 
 enum { CLS_QKV = 0, CLS_RESID = 1, CLS_GELU = 2 };
 
-template <int DT, int EPI>
+// U = k steps (of 32) per batch of loads: a wave requests 3 U fragments (weight + two row blocks) before the first MFMA of the batch, so
+// a batch costs ONE L2 round trip (hipcc does not unroll the run-time k loop by itself: one round trip per k step, 32 in a row for fc2)
+template <int DT, int EPI, int U>
 __global__ __launch_bounds__(256) void cls_linear_kernel(const ClsArgs a) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
@@ -47,14 +49,20 @@ __global__ __launch_bounds__(256) void cls_linear_kernel(const ClsArgs a) {
     const int kq = a.K >> 2, k0 = w * kq;
     const int awrap = a.a_k > 0 ? a.a_k : a.K;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int kk = k0; kk < k0 + kq; kk += 32) {
+    for (int kk = k0; kk < k0 + kq; kk += 32 * U) {          // (a batch never straddles the wrap point: a_k % (32 U) == 0, launcher)
         const int ka = kk >= awrap ? kk - awrap : kk;
-        const V8 wf = *(const V8*)(wp + kk);
-        const V8 x0 = *(const V8*)(a0p + ka);
-        const V8 x1 = *(const V8*)(a1p + ka);
-        acc0 = Op<DT>::mfma16(wf, x0, acc0);
-        acc1 = Op<DT>::mfma16(wf, x1, acc1);
+        V8 wf[U], x0[U], x1[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            wf[i] = *(const V8*)(wp + kk + 32 * i);
+            x0[i] = *(const V8*)(a0p + ka + 32 * i);
+            x1[i] = *(const V8*)(a1p + ka + 32 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            acc0 = Op<DT>::mfma16(wf[i], x0[i], acc0);
+            acc1 = Op<DT>::mfma16(wf[i], x1[i], acc1);
+        }
     }
     if (w > 0) { red[w - 1][0][lane] = acc0; red[w - 1][1][lane] = acc1; }
     __syncthreads();
@@ -97,17 +105,26 @@ __global__ __launch_bounds__(256) void cls_linear_kernel(const ClsArgs a) {
     }
 }
 
-template <int DT>
-int launch_cls(const ClsArgs& a, int epi, hipStream_t s) {
+template <int DT, int U>
+int launch_cls_u(const ClsArgs& a, int epi, hipStream_t s) {
     const dim3 grid(a.N / 16, (a.B + 31) / 32);
     switch (epi) {
-        case CLS_QKV: hipLaunchKernelGGL((cls_linear_kernel<DT, CLS_QKV>), grid, dim3(256), 0, s, a); break;
-        case CLS_RESID: hipLaunchKernelGGL((cls_linear_kernel<DT, CLS_RESID>), grid, dim3(256), 0, s, a); break;
-        case CLS_GELU: hipLaunchKernelGGL((cls_linear_kernel<DT, CLS_GELU>), grid, dim3(256), 0, s, a); break;
+        case CLS_QKV: hipLaunchKernelGGL((cls_linear_kernel<DT, CLS_QKV, U>), grid, dim3(256), 0, s, a); break;
+        case CLS_RESID: hipLaunchKernelGGL((cls_linear_kernel<DT, CLS_RESID, U>), grid, dim3(256), 0, s, a); break;
+        case CLS_GELU: hipLaunchKernelGGL((cls_linear_kernel<DT, CLS_GELU, U>), grid, dim3(256), 0, s, a); break;
         default: return MHMR_ERR_BAD_ARG;
     }
     MHMR_CHECK_LAUNCH();
     return 0;
+}
+
+template <int DT>
+int launch_cls(const ClsArgs& a, int epi, hipStream_t s) {
+    // the largest batch that divides a wave's k quarter and the wrap point: 8 steps (C = 1024), 6 (C = 768), else one step at a time
+    const int kq = a.K / 4, wrap = a.a_k > 0 ? a.a_k : kq;
+    if (kq % 256 == 0 && wrap % 256 == 0) return launch_cls_u<DT, 8>(a, epi, s);
+    if (kq % 192 == 0 && wrap % 192 == 0) return launch_cls_u<DT, 6>(a, epi, s);
+    return launch_cls_u<DT, 1>(a, epi, s);
 }
 
 }  // namespace

@@ -246,12 +246,19 @@ class Model(nn.Module):
         self.embed_dim, self.patch_size = self.backbone.embed_dim, self.backbone.patch_size
         assert self.img_size % self.patch_size == 0, "Invalid img size"
         self.fovn = 60
+        # camera embedding (reference model.py:67-83).  None is accepted by the constructor exactly as the reference accepts it
+        # (camera_embed_dim = 0, no `camera` module) -- and, as in the reference, such a model cannot run forward(): model.py:262 calls
+        # embedd_camera() unconditionally, which needs self.camera (AttributeError there, AttributeError here).
         self.camera_embedding = camera_embedding
-        if camera_embedding != "geometric":
-            raise NotImplementedError("Only geometric camera embedding is implemented")
-        if camera_embedding_num_bands != 16 or camera_embedding_max_resolution != 64:
-            raise NotImplementedError("camera embedding kernel is built for 16 bands / max resolution 64 (all released checkpoints)")
-        self.camera_embed_dim = 3 + 2 * 3 * camera_embedding_num_bands   # 99
+        self.camera_embed_dim = 0
+        self._camera_max_resolution = camera_embedding_max_resolution
+        if camera_embedding is not None:
+            if camera_embedding != "geometric":
+                raise NotImplementedError("Only geometric camera embedding is implemented")
+            if camera_embedding_num_bands != 16:
+                raise NotImplementedError("the camera embedding kernel lays out 3 + 2*3*16 = 99 channels (camera_embedding_num_bands = 16, "
+                                          "what every released checkpoint uses); any camera_embedding_max_resolution is supported")
+            self.camera_embed_dim = 3 + 2 * 3 * camera_embedding_num_bands   # 99
         self.mlp_classif = nn.Sequential(nn.Linear(self.embed_dim, self.embed_dim), nn.ReLU(), nn.Linear(self.embed_dim, 1))
         self.mlp_offset = nn.Sequential(nn.Linear(self.embed_dim, self.embed_dim), nn.ReLU(), nn.Linear(self.embed_dim, 2))
         self.nrot = 53
@@ -262,7 +269,8 @@ class Model(nn.Module):
                                     heads=xat_num_heads, mlp_dim=1024, dim_head=32, at_token_res=img_size // PATCH,
                                     num_betas=num_betas, mean_params=_load_mean_params(kwargs.get("mean_params")))
         self._packed = None                 # tensors + descriptors of the current (device, precision, parameters)
-        self._ws = vit.WorkspaceCache()     # the workspace of the most recent batch size
+        self._ws = vit.WorkspaceCache()     # the workspaces of the most recent batch sizes
+        self._idx_counts = None             # (identity of the last training-hook idx[0], its per-image counts on the host)
         for p in self.parameters():
             p.requires_grad_(False)
 
@@ -300,7 +308,8 @@ class Model(nn.Module):
         P["Cc"], P["Kc"] = Cc, Kc
         P["cls0_w"], P["cls0_b"] = op(self.mlp_classif[0].weight), f32(self.mlp_classif[0].bias)
         P["cls2_w"], P["cls2_b"] = f32(self.mlp_classif[2].weight.reshape(-1)), f32(self.mlp_classif[2].bias)
-        P["freq"] = torch.stack([torch.linspace(1.0, 64 / 2, 16) for _ in range(3)]).to(device).contiguous()
+        # blocks/camera_embed.py:46: linspace(1, max_resolution / 2, num_bands) per ray component
+        P["freq"] = torch.stack([torch.linspace(1.0, self._camera_max_resolution / 2, 16) for _ in range(3)]).to(device).contiguous()
 
         # HPH
         hp = self.x_attention_head
@@ -361,6 +370,9 @@ class Model(nn.Module):
         return ws["feat32"].view(x.shape[0], P["N"], P["C"])
 
     def _prepare(self, x):
+        if self.camera_embedding is None:
+            raise AttributeError("'Model' object has no attribute 'camera' (camera_embedding=None: the reference's forward fails the same "
+                                 "way at model.py:262 -> :183)")
         if not x.is_cuda:
             raise _lib.MhmrError("multi_hmr_amd.Model.forward runs only on an MI355X (HIP) tensor; there is no CPU fallback")
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != self.img_size or x.shape[3] != self.img_size:
@@ -386,6 +398,16 @@ class Model(nn.Module):
         L = _lib.lib()
         P, ws, stream = self._prepare(x)
         dev, B, G, N, Cdim, Kc = x.device, x.shape[0], P["G"], P["N"], P["C"], P["Kc"]
+        if is_training:
+            # the per-image person counts are needed on the HOST (ragged query groups below).  Taken BEFORE the first launch -- a
+            # device-resident idx read back after the backbone was enqueued would stall the host until the backbone has finished, with
+            # the head kernels not yet in the queue -- and remembered for an idx tensor that is handed in again unchanged.
+            assert idx is not None
+            i0 = idx[0]
+            key = (i0.data_ptr(), i0._version, tuple(i0.shape), str(i0.device), B)
+            if self._idx_counts is None or self._idx_counts[0] != key:
+                self._idx_counts = (key, torch.bincount(i0.detach().cpu().long(), minlength=B))
+            counts_pinned = self._idx_counts[1]
         dt = P["dt_id"]
         K = K.to(device=dev, dtype=torch.float32).contiguous()
         assert K.shape == (B, 3, 3)
@@ -420,29 +442,32 @@ class Model(nn.Module):
                                            det[2].data_ptr(), scores_det.data_ptr(), stream), "mhmr_detect_write")
             idx = (det[0].long(), det[1].long(), det[2].long(), torch.zeros(Pn, dtype=torch.long, device=dev))
         else:
-            assert idx is not None
             idx = tuple(i.to(dev) for i in idx)
             Pn = int(idx[0].shape[0])
             det = torch.stack([idx[0], idx[1], idx[2]]).to(torch.int32).contiguous()
-            counts = torch.bincount(idx[0].cpu(), minlength=B)
+            counts = counts_pinned
             scores_det = None
         out = {"scores": scores.clone() if is_training else scores}
         if Pn == 0:
             return out
 
         # 5. ragged query groups (rebatch / pad_to_max semantics, utils/tensor_manip.py:7-45, without the padding)
-        cl = [int(c) for c in counts.tolist()]
-        gstart, chunks, start = [0], [], 0
-        for b, c in enumerate(cl):
-            if c == 0:
-                continue
-            for q0 in range(0, c, 8):
-                chunks += [b, start + q0, min(8, c - q0)]
-            start += c
-            gstart.append(start)
-        nmax = max(cl)
-        meta = torch.tensor(gstart + chunks, dtype=torch.int32).to(dev)
-        gstart_t, chunks_t = meta[: len(gstart)], meta[len(gstart):]
+        groups = self._idx_counts[2] if (is_training and len(self._idx_counts) > 2) else None
+        if groups is None:
+            cl = [int(c) for c in counts.tolist()]
+            gstart, chunks, start = [0], [], 0
+            for b, c in enumerate(cl):
+                if c == 0:
+                    continue
+                for q0 in range(0, c, 8):
+                    chunks += [b, start + q0, min(8, c - q0)]
+                start += c
+                gstart.append(start)
+            meta = torch.tensor(gstart + chunks, dtype=torch.int32).to(dev)
+            groups = (meta[: len(gstart)], meta[len(gstart):], len(gstart) - 1, len(chunks) // 3, max(cl))
+            if is_training:
+                self._idx_counts = self._idx_counts[:2] + (groups,)
+        gstart_t, chunks_t, ngroups, nchunks, nmax = groups
 
         # 6. HPH (model.py:258-283, 287-298)
         h = P["hph"]
@@ -466,8 +491,8 @@ class Model(nn.Module):
         shape, expression = f(Pn, h["nb"]), f(Pn, 10)
         dist_pp, dist = f(Pn, 1), f(Pn, 1)
         _lib.check(L.mhmr_hph_forward(C.byref(d), ws["feat32"].data_ptr(), ws["zK"].data_ptr(), ws["ctx16"].data_ptr(), det[0].data_ptr(),
-                                      det[1].data_ptr(), det[2].data_ptr(), Pn, gstart_t.data_ptr(), len(gstart) - 1, nmax,
-                                      chunks_t.data_ptr(), len(chunks) // 3, K.data_ptr(), B, offset.data_ptr(), loc.data_ptr(),
+                                      det[1].data_ptr(), det[2].data_ptr(), Pn, gstart_t.data_ptr(), ngroups, nmax,
+                                      chunks_t.data_ptr(), nchunks, K.data_ptr(), B, offset.data_ptr(), loc.data_ptr(),
                                       rotmat.data_ptr(), rotvec.data_ptr(), shape.data_ptr(), expression.data_ptr(), dist_pp.data_ptr(),
                                       dist.data_ptr(), stream), "mhmr_hph_forward")
 

@@ -106,22 +106,26 @@ def padded_tokens(P: dict, B: int) -> int:
 
 
 class WorkspaceCache:
-    """ONE cached workspace: the one of the most recent (pack, batch size).  A different batch size or a repack (load_state_dict,
-    .to(), repack()) replaces it, so a descriptor never outlives the tensors its raw pointers refer to and a model does not pin a
-    multi-GB workspace per batch size it has ever seen."""
+    """The workspaces of the TWO most recent (pack, batch size) pairs: a run whose last batch of an epoch is smaller alternates between
+    two batch sizes without re-allocating (and zero-filling) a multi-GB workspace at every switch, while a model does not pin one per
+    batch size it has ever seen.  A repack (load_state_dict, .to(), repack()) drops everything, so a descriptor never outlives the
+    tensors its raw pointers refer to."""
+    KEEP = 2
 
     def __init__(self):
-        self._key, self._ws = None, None
+        self._ws = {}          # key -> workspace, oldest first
 
     def clear(self):
-        self._key, self._ws = None, None
+        self._ws = {}
 
     def get(self, P: dict, B: int, extra):
         """extra(P, B, z) -> dict of additional workspace tensors (z = zero-tensor factory in the operand dtype)."""
         key = (id(P), B)
-        if self._key == key:
-            return self._ws
-        self._ws = None                                   # free the old one before allocating
+        if key in self._ws:
+            self._ws[key] = self._ws.pop(key)             # most recent last
+            return self._ws[key]
+        while len(self._ws) >= self.KEEP:                 # free the oldest before allocating
+            self._ws.pop(next(iter(self._ws)))
         dev, tdt = P["device"], P["tdt"]
         Cd, N, Tp, H = P["C"], P["N"], padded_tokens(P, B), P["H"]
         Mp = roundup(B * N, 128)
@@ -140,5 +144,5 @@ class WorkspaceCache:
         for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid", "attn_flags"):
             setattr(d, n, ws[n].data_ptr())
         ws["vit_desc"], ws["Tp"] = d, Tp
-        self._key, self._ws = key, ws
+        self._ws[key] = ws
         return ws

@@ -15,7 +15,45 @@ import numpy as np
 import torch
 from torch import nn
 
-from multi_hmr_amd.constants import SMPLX_EXTRA_JOINT_VERTS, SMPLX_JOINT_NAMES
+# The oracle keeps its OWN literal copy of the smplx tables (smplx/vertex_ids.py['smplx'], smplx/joint_names.py): a wrong id in the
+# product's multi_hmr_amd/constants.py must show up as a parity failure, not be wrong on both sides
+# (tests/test_oracle_thirdparty.py::test_smplx_tables_of_oracle_and_product_agree compares the two copies).
+SMPLX_EXTRA_JOINT_VERTS = [
+    9120,  # nose
+    9929,  # reye
+    9448,  # leye
+    616,   # rear
+    6,     # lear
+    5770,  # LBigToe
+    5780,  # LSmallToe
+    8846,  # LHeel
+    8463,  # RBigToe
+    8474,  # RSmallToe
+    8635,  # RHeel
+    5361,  # lthumb
+    4933,  # lindex
+    5058,  # lmiddle
+    5169,  # lring
+    5286,  # lpinky
+    8079,  # rthumb
+    7669,  # rindex
+    7794,  # rmiddle
+    7905,  # rring
+    8022,  # rpinky
+]
+SMPLX_JOINT_NAMES = [
+    "pelvis", "left_hip", "right_hip", "spine1", "left_knee", "right_knee", "spine2", "left_ankle", "right_ankle", "spine3", "left_foot",
+    "right_foot", "neck", "left_collar", "right_collar", "head", "left_shoulder", "right_shoulder", "left_elbow", "right_elbow",
+    "left_wrist", "right_wrist", "jaw", "left_eye_smplhf", "right_eye_smplhf",
+    "left_index1", "left_index2", "left_index3", "left_middle1", "left_middle2", "left_middle3", "left_pinky1", "left_pinky2",
+    "left_pinky3", "left_ring1", "left_ring2", "left_ring3", "left_thumb1", "left_thumb2", "left_thumb3",
+    "right_index1", "right_index2", "right_index3", "right_middle1", "right_middle2", "right_middle3", "right_pinky1", "right_pinky2",
+    "right_pinky3", "right_ring1", "right_ring2", "right_ring3", "right_thumb1", "right_thumb2", "right_thumb3",
+    "nose", "right_eye", "left_eye", "right_ear", "left_ear", "left_big_toe", "left_small_toe", "left_heel", "right_big_toe",
+    "right_small_toe", "right_heel", "left_thumb", "left_index", "left_middle", "left_ring", "left_pinky", "right_thumb", "right_index",
+    "right_middle", "right_ring", "right_pinky",
+] + [f"face_landmark_{i}" for i in range(51)]                 # the first 127 of smplx.joint_names.JOINT_NAMES (utils/humans.py:25-26)
+assert len(SMPLX_JOINT_NAMES) == 127
 
 JOINT_NAMES = list(SMPLX_JOINT_NAMES) + [f"contour_{i}" for i in range(17)]  # smplx.joint_names.JOINT_NAMES
 

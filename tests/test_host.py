@@ -84,6 +84,21 @@ def test_model_surface_matches_reference(smplx_data, mean_params):
     assert m.state_dict()["x_attention_head.transformer.transformer.layers.1.1.fn.to_kv.weight"].shape == (512, 483)
 
 
+def test_camera_embedding_constructor_contract(smplx_data, mean_params):
+    """Reference model.py:67-83: camera_embedding=None is accepted by the constructor (camera_embed_dim = 0, context = features only) but
+    such a model cannot run forward (model.py:262 calls embedd_camera unconditionally -> AttributeError on self.camera); anything but
+    'geometric' / None raises NotImplementedError; camera_embedding_max_resolution only sets the frequency table."""
+    kw = dict(backbone="dinov2_vits14", img_size=224, smplx_data=smplx_data, mean_params=mean_params, backbone_depth=1)
+    m = Model(camera_embedding=None, **kw)
+    assert m.camera_embed_dim == 0 and m.state_dict()["x_attention_head.cross_queries_x"].shape == (16, 384)
+    assert m.state_dict()["x_attention_head.transformer.to_token_embedding.weight"].shape == (1024, 318 + 10 + 3 + 384)
+    with pytest.raises(AttributeError):
+        m(torch.zeros(1, 3, 224, 224), K=synthetic.get_camera_K(224))
+    with pytest.raises(NotImplementedError):
+        Model(camera_embedding="learned", **kw)
+    assert Model(camera_embedding_max_resolution=128, **kw).camera_embed_dim == 99
+
+
 def test_no_cpu_fallback(smplx_data, mean_params):
     m = Model(backbone="dinov2_vits14", img_size=224, smplx_data=smplx_data, mean_params=mean_params, backbone_depth=1)
     with pytest.raises(_lib.MhmrError):

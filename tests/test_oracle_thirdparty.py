@@ -157,3 +157,13 @@ def test_lbs_one_hot_weights_single_joint(smplx_data):
     still = torch.from_numpy(~np.isin(owner, list(moved)))
     assert torch.allclose(out.vertices[0, still], rest.vertices[0, still], atol=1e-6)
     assert (out.vertices[0, ~still] - rest.vertices[0, ~still]).abs().max() > 1e-3
+
+
+def test_smplx_tables_of_oracle_and_product_agree():
+    """oracle/smplx_ref.py and multi_hmr_amd/constants.py each hold their own literal copy of the smplx vertex ids / joint names
+    (so that a wrong id on one side is a parity failure); this is the one place where the two are compared."""
+    from multi_hmr_amd import constants
+    from oracle import smplx_ref
+    assert list(smplx_ref.SMPLX_EXTRA_JOINT_VERTS) == list(constants.SMPLX_EXTRA_JOINT_VERTS) and len(smplx_ref.SMPLX_EXTRA_JOINT_VERTS) == 21
+    assert list(smplx_ref.SMPLX_JOINT_NAMES) == list(constants.SMPLX_JOINT_NAMES)
+    assert smplx_ref.SMPLX_JOINT_NAMES[15] == "head" and smplx_ref.SMPLX_JOINT_NAMES[55] == "nose" and smplx_ref.SMPLX_JOINT_NAMES[0] == "pelvis"
