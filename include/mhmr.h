@@ -64,6 +64,12 @@ typedef struct {
      * op16 [C, 2C] = [W_hi | W_lo] along k with W_hi = op16(W), W_lo = op16(W - W_hi); NULL = single pass over qkv_w[2C:3C] / proj_w. */
     const void* v_w2;             /* blocks.i.attn.qkv.weight[2C:3C] as hi | lo, or NULL              */
     const void* proj_w2;          /* blocks.i.attn.proj.weight as hi | lo, or NULL                    */
+    /* LayerNorm folded into the consuming linear (used when mhmr_vit_desc.pstats / rowstats are given and the token-row map is on):
+     * flags bit 0: norm1 -> qkv, bit 1: norm2 -> fc1.  A folded linear's weight is W diag(w_ln) (v_w2 likewise), its bias is
+     * b + W b_ln, and *_colsum[n] = sum_k of the ROUNDED folded weight row (hi + lo where there is a low half), fp32. */
+    int flags;
+    const float* qkv_colsum;      /* [3C] or NULL */
+    const float* fc1_colsum;      /* [4C] or NULL */
 } mhmr_vit_block;
 
 typedef struct {
@@ -89,6 +95,11 @@ typedef struct {
     void* att;              /* op16 [B*Tp, C]                                                             */
     void* hid;              /* op16 [B*Tp, 4C]                                                            */
     int* attn_flags;        /* [mhmr_attention_flag_count(B, Tp, H)] or NULL (then the self-contained attention form runs) */
+    /* LayerNorm fold workspaces, or NULL (then every LayerNorm is a pass of its own and no block may have flags set): the residual
+     * epilogues of proj / fc2 leave the 16-bit copy of the raw residual rows in `xn` and per-row block sums in `pstats`; row statistics
+     * are finished by a small kernel into `rowstats`; the consuming linears normalise in their epilogues. */
+    float* pstats;          /* [B*Tp, C/64, 2]  (sum, sum of squares) of every 64-column block of a residual row               */
+    float* rowstats;        /* [B*Tp, 2]        (mean, rstd)                                                                  */
 } mhmr_vit_desc;
 
 /* x: [B,3,S,S] fp32 (ImageNet-normalised).  feat32: [B*N, C] fp32 patch features (token n = y*G + x).
@@ -105,6 +116,16 @@ int mhmr_gemm16(const void* A, int lda, const void* W, int ldw, int M, int N, in
 int mhmr_gemm16_ex(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias,
                    const float* gamma, void* out, int ldo, const float* pos, int Np, int Tp, int H, int Mvalid, int epi,
                    int dtype, int img_rows, int img_stride, int a_k, void* stream);
+/* mhmr_gemm16_ex with the LayerNorm fold (csrc/gemm256.hip; M, N % 256 == 0, K % 128 == 0 only).  Producer (epi = MHMR_EPI_RESID): x16 !=
+ * NULL receives the op16 copy of the updated residual rows [rows, N] and pstats [rows, N/64, 2] the (sum, sum of squares) of each
+ * 64-column block.  Consumer (epi = MHMR_EPI_OP16_QK / _VT / _OP16_GELU, bias = NULL): out = rstd_m (acc - mean_m colsum_n) + fbias_n
+ * with rowstats [rows, 2] = (mean, rstd) as mhmr_ln_stats leaves them.                                                              */
+int mhmr_gemm16_ln(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias,
+                   const float* gamma, void* out, int ldo, int Tp, int H, int epi, int dtype, int img_rows, int img_stride,
+                   int a_k, void* x16, float* pstats, const float* rowstats, const float* colsum, const float* fbias, void* stream);
+/* rowstats[b*Tp + n] = (mean, rstd) of residual row (b, n): n < N from the block sums pstats[b*Tp + n][C/64][2], n == N (the class row)
+ * from the fp32 row resid[b*Tp + N][C] itself.                                                                                       */
+int mhmr_ln_stats(const float* pstats, const float* resid, float* rowstats, int B, int N, int Tp, int C, float eps, void* stream);
 /* The class-token rows of a block linear (csrc/vit_cls.hip): B rows, a_stride / o_stride elements apart.  epi 0: Q | K | V projection
  * (columns n_base + [0, N) of [Q * MHMR_ATTN_QSCALE | K | V]; Q, K -> out16 row, V -> column vcol of vt [B,H,64,Tp]); epi 1: out32 +=
  * gamma * (acc + bias); epi 2: out16 = gelu(acc + bias).  N % 16 == 0, K % 128 == 0, a_k as in mhmr_gemm16_ex.                     */

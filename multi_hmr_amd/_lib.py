@@ -70,15 +70,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 class VitBlock(C.Structure):
-    _fields_ = [(n, _vp) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1", "ln2_w", "ln2_b",
-                                   "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "v_w2", "proj_w2")]
+    _fields_ = ([(n, _vp) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1", "ln2_w", "ln2_b",
+                                    "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "v_w2", "proj_w2")] +
+                [("flags", _i), ("qkv_colsum", _vp), ("fc1_colsum", _vp)])
 
 
 class VitDesc(C.Structure):
     _fields_ = ([(n, _i) for n in ("dtype", "B", "S", "C", "H", "L", "G", "N", "T", "Tp", "Kp")] +
                 [("patch_w", _vp), ("patch_b", _vp), ("cls_pos0", _vp), ("pos", _vp), ("blocks", C.POINTER(VitBlock)),
                  ("norm_w", _vp), ("norm_b", _vp)] +
-                [(n, _vp) for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid", "attn_flags")])
+                [(n, _vp) for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid", "attn_flags", "pstats", "rowstats")])
 
 
 class HphLayer(C.Structure):
@@ -104,6 +105,8 @@ _SIGS = {
     "mhmr_vit_forward": ([C.POINTER(VitDesc), _vp, _vp, _vp, _i, _vp], _i),
     "mhmr_gemm16": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mhmr_gemm16_ex": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "mhmr_gemm16_ln": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "mhmr_ln_stats": ([_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
     "mhmr_cls_linear16": ([_vp, C.c_longlong, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, C.c_longlong, _i, _i, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "mhmr_attention16": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mhmr_attention16_ex": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp], _i),

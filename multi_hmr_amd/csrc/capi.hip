@@ -27,6 +27,11 @@ int mhmr_launch_hph_decode(const float* dec, int ldd, int nb, const float* Kmat,
 int mhmr_launch_cls_linear(const void* A, long long a_stride, const void* W, int ldw, int B, int N, int K, int a_k, const float* bias,
                            const float* gamma, void* out, long long o_stride, int n_base, int C, void* vt, int H, int Tp, int vcol, int epi,
                            int dtype, hipStream_t s);
+int mhmr_launch_cls_linear_fold(const void* A, long long a_stride, const void* W, int ldw, int B, int N, int K, int a_k, const float* bias,
+                                const float* gamma, void* out, long long o_stride, int n_base, int C, void* vt, int H, int Tp, int vcol, int epi,
+                                int dtype, const float* rowstats, long long rs_stride, const float* colsum, const float* fbias, void* x16,
+                                long long x_stride, hipStream_t s);
+int mhmr_launch_ln_stats(const float* pstats, const float* resid, float* rowstats, int B, int N, int Tp, int C, float eps, hipStream_t s);
 int mhmr_launch_loc(const float* offset, const int* det_y, const int* det_x, int patch, float* loc, int P, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------ profiler
@@ -114,6 +119,25 @@ int mhmr_gemm16_ex(const void* A, int lda, const void* W, int ldw, int M, int N,
     return mhmr_launch_gemm(g, dtype, (hipStream_t)stream);
 }
 
+int mhmr_gemm16_ln(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, const float* gamma, void* out,
+                   int ldo, int Tp, int H, int epi, int dtype, int img_rows, int img_stride, int a_k, void* x16, float* pstats,
+                   const float* rowstats, const float* colsum, const float* fbias, void* stream) {
+    GemmArgs g{A, lda, W, ldw, M, N, K, bias, gamma, out, ldo, nullptr, 0, Tp, H, M, epi};
+    g.img_rows = img_rows;
+    g.img_stride = img_stride;
+    g.a_k = a_k;
+    g.x16 = x16;
+    g.pstats = pstats;
+    g.rowstats = rowstats;
+    g.colsum = colsum;
+    g.fbias = fbias;
+    return mhmr_launch_gemm(g, dtype, (hipStream_t)stream);
+}
+
+int mhmr_ln_stats(const float* pstats, const float* resid, float* rowstats, int B, int N, int Tp, int C, float eps, void* stream) {
+    return mhmr_launch_ln_stats(pstats, resid, rowstats, B, N, Tp, C, eps, (hipStream_t)stream);
+}
+
 int mhmr_cls_linear16(const void* A, long long a_stride, const void* W, int ldw, int B, int N, int K, int a_k, const float* bias,
                       const float* gamma, void* out, long long o_stride, int n_base, int C, void* vt, int H, int Tp, int vcol, int epi,
                       int dtype, void* stream) {
@@ -166,34 +190,46 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
         TRY(mhmr_launch_gemm(g, dt, s));
     }
     auto rows = [&](GemmArgs& g) { g.img_rows = ir; g.img_stride = is; };
+    // LayerNorm fold (GemmArgs in mhmr_internal.h): needs the token-row map (every block linear on the 256x256 kernel) and the two workspaces
+    static const bool fold_env = !(getenv("MHMR_LNFOLD") && atoi(getenv("MHMR_LNFOLD")) == 0);
+    const bool fold = rowmap && fold_env && d->pstats && d->rowstats;
+    const long long rowC = (long long)Tp * C;
+    const float* cls_stats = fold ? d->rowstats + (size_t)cls_row * 2 : nullptr;      // (mean, rstd) of image b's class row: + b * 2 Tp
     for (int l = 0; l < d->L; ++l) {
         const mhmr_vit_block& k = d->blocks[l];
+        if (!fold && k.flags) return MHMR_ERR_BAD_ARG;               // folded weights cannot run through the plain LayerNorm path
+        const bool f1 = fold && (k.flags & 1), f2 = fold && (k.flags & 2);
         // the V and output projections may carry the low halves of their weights ([W_hi | W_lo] along k, one accumulator chain)
         const void* v_w = k.v_w2 ? k.v_w2 : (const void*)((const char*)k.qkv_w + (size_t)2 * C * C * esz);
         const int v_k = k.v_w2 ? 2 * C : C, v_ak = k.v_w2 ? C : 0;
         const void* p_w = k.proj_w2 ? k.proj_w2 : k.proj_w;
         const int p_k = k.proj_w2 ? 2 * C : C, p_ak = k.proj_w2 ? C : 0;
         // x = x + ls1 * proj(MHSA(norm1(x)))
-        TRY(mhmr_launch_layernorm(d->resid, k.ln1_w, k.ln1_b, d->xn, M, C, 1e-6f, dt, s));
+        if (f1) TRY(mhmr_launch_ln_stats(d->pstats, d->resid, d->rowstats, B, N, Tp, C, 1e-6f, s));
+        else TRY(mhmr_launch_layernorm(d->resid, k.ln1_w, k.ln1_b, d->xn, M, C, 1e-6f, dt, s));
         {
             GemmArgs g{d->xn, C, k.qkv_w, C, Mg, 2 * C, C, k.qkv_b, nullptr, d->qk, 2 * C, nullptr, 0, Tp, d->H, Mg, EPI_OP16_QK};
             GemmArgs gv{d->xn, C, v_w, v_k, Mg, C, v_k, k.qkv_b + 2 * C, nullptr, d->vt, 0, nullptr, 0, Tp, d->H, Mg, EPI_VT};
             gv.a_k = v_ak;
             rows(g); rows(gv);
+            if (f1) {
+                g.bias = nullptr; g.rowstats = d->rowstats; g.colsum = k.qkv_colsum; g.fbias = k.qkv_b;
+                gv.bias = nullptr; gv.rowstats = d->rowstats; gv.colsum = k.qkv_colsum + 2 * C; gv.fbias = k.qkv_b + 2 * C;
+            }
             TRY(mhmr_launch_gemm(g, dt, s));
             TRY(mhmr_launch_gemm(gv, dt, s));
             if (rowmap) {
                 const char* xr = (const char*)d->xn + (size_t)cls_row * C * esz;
                 char* qr = (char*)d->qk + (size_t)cls_row * 2 * C * esz;
-                if (k.v_w2) {
-                    TRY(mhmr_launch_cls_linear(xr, (long long)Tp * C, k.qkv_w, C, B, 2 * C, C, 0, k.qkv_b, nullptr, qr, (long long)Tp * 2 * C, 0, C,
-                                               d->vt, d->H, Tp, vcol, 0, dt, s));
-                    TRY(mhmr_launch_cls_linear(xr, (long long)Tp * C, v_w, v_k, B, C, v_k, v_ak, k.qkv_b + 2 * C, nullptr, qr, (long long)Tp * 2 * C,
-                                               2 * C, C, d->vt, d->H, Tp, vcol, 0, dt, s));
-                } else {
-                    TRY(mhmr_launch_cls_linear(xr, (long long)Tp * C, k.qkv_w, C, B, 3 * C, C, 0, k.qkv_b, nullptr, qr, (long long)Tp * 2 * C, 0, C,
-                                               d->vt, d->H, Tp, vcol, 0, dt, s));
-                }
+                const float* st = f1 ? cls_stats : nullptr;
+                // (Q | K and V separately when V carries a low half: different k extents)
+                const int nqk = k.v_w2 ? 2 * C : 3 * C;
+                TRY(mhmr_launch_cls_linear_fold(xr, rowC, k.qkv_w, C, B, nqk, C, 0, f1 ? nullptr : k.qkv_b, nullptr, qr, 2 * rowC, 0, C, d->vt, d->H,
+                                                Tp, vcol, 0, dt, st, 2LL * Tp, k.qkv_colsum, k.qkv_b, nullptr, 0, s));
+                if (k.v_w2)
+                    TRY(mhmr_launch_cls_linear_fold(xr, rowC, v_w, v_k, B, C, v_k, v_ak, f1 ? nullptr : k.qkv_b + 2 * C, nullptr, qr, 2 * rowC, 2 * C, C,
+                                                    d->vt, d->H, Tp, vcol, 0, dt, st, 2LL * Tp, f1 ? k.qkv_colsum + 2 * C : nullptr,
+                                                    k.qkv_b + 2 * C, nullptr, 0, s));
             }
         }
         TRY(mhmr_launch_attention(d->qk, d->vt, d->att, B, d->T, Tp, C, d->H, dt, d->attn_flags, s));
@@ -201,28 +237,33 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
             GemmArgs g{d->att, C, p_w, p_k, Mg, C, p_k, k.proj_b, k.ls1, d->resid, C, nullptr, 0, Tp, d->H, Mg, EPI_RESID};
             g.a_k = p_ak;
             rows(g);
+            if (fold) { g.x16 = d->xn; g.pstats = d->pstats; }
             TRY(mhmr_launch_gemm(g, dt, s));
             if (rowmap)
-                TRY(mhmr_launch_cls_linear((const char*)d->att + (size_t)cls_row * C * esz, (long long)Tp * C, p_w, p_k, B, C, p_k, p_ak, k.proj_b,
-                                           k.ls1, d->resid + (size_t)cls_row * C, (long long)Tp * C, 0, C, nullptr, d->H, Tp, 0, 1, dt, s));
+                TRY(mhmr_launch_cls_linear_fold((const char*)d->att + (size_t)cls_row * C * esz, rowC, p_w, p_k, B, C, p_k, p_ak, k.proj_b, k.ls1,
+                                                d->resid + (size_t)cls_row * C, rowC, 0, C, nullptr, d->H, Tp, 0, 1, dt, nullptr, 0, nullptr, nullptr,
+                                                fold ? (char*)d->xn + (size_t)cls_row * C * esz : nullptr, rowC, s));
         }
         // x = x + ls2 * fc2(gelu(fc1(norm2(x))))
-        TRY(mhmr_launch_layernorm(d->resid, k.ln2_w, k.ln2_b, d->xn, M, C, 1e-6f, dt, s));
+        if (f2) TRY(mhmr_launch_ln_stats(d->pstats, d->resid, d->rowstats, B, N, Tp, C, 1e-6f, s));
+        else TRY(mhmr_launch_layernorm(d->resid, k.ln2_w, k.ln2_b, d->xn, M, C, 1e-6f, dt, s));
         {
             GemmArgs g{d->xn, C, k.fc1_w, C, Mg, 4 * C, C, k.fc1_b, nullptr, d->hid, 4 * C, nullptr, 0, Tp, d->H, Mg, EPI_OP16_GELU};
             rows(g);
+            if (f2) { g.bias = nullptr; g.rowstats = d->rowstats; g.colsum = k.fc1_colsum; g.fbias = k.fc1_b; }
             TRY(mhmr_launch_gemm(g, dt, s));
             if (rowmap)
-                TRY(mhmr_launch_cls_linear((const char*)d->xn + (size_t)cls_row * C * esz, (long long)Tp * C, k.fc1_w, C, B, 4 * C, C, 0, k.fc1_b,
-                                           nullptr, (char*)d->hid + (size_t)cls_row * 4 * C * esz, (long long)Tp * 4 * C, 0, C, nullptr, d->H, Tp, 0,
-                                           2, dt, s));
+                TRY(mhmr_launch_cls_linear_fold((const char*)d->xn + (size_t)cls_row * C * esz, rowC, k.fc1_w, C, B, 4 * C, C, 0, f2 ? nullptr : k.fc1_b,
+                                                nullptr, (char*)d->hid + (size_t)cls_row * 4 * C * esz, 4 * rowC, 0, C, nullptr, d->H, Tp, 0, 2, dt,
+                                                f2 ? cls_stats : nullptr, 2LL * Tp, k.fc1_colsum, k.fc1_b, nullptr, 0, s));
             GemmArgs g2{d->hid, 4 * C, k.fc2_w, 4 * C, Mg, C, 4 * C, k.fc2_b, k.ls2, d->resid, C, nullptr, 0, Tp, d->H, Mg, EPI_RESID};
             rows(g2);
+            if (fold) { g2.x16 = d->xn; g2.pstats = d->pstats; }
             TRY(mhmr_launch_gemm(g2, dt, s));
             if (rowmap)
-                TRY(mhmr_launch_cls_linear((const char*)d->hid + (size_t)cls_row * 4 * C * esz, (long long)Tp * 4 * C, k.fc2_w, 4 * C, B, C, 4 * C,
-                                           0, k.fc2_b, k.ls2, d->resid + (size_t)cls_row * C, (long long)Tp * C, 0, C, nullptr, d->H, Tp, 0, 1, dt,
-                                           s));
+                TRY(mhmr_launch_cls_linear_fold((const char*)d->hid + (size_t)cls_row * 4 * C * esz, 4 * rowC, k.fc2_w, 4 * C, B, C, 4 * C, 0, k.fc2_b,
+                                                k.ls2, d->resid + (size_t)cls_row * C, rowC, 0, C, nullptr, d->H, Tp, 0, 1, dt, nullptr, 0, nullptr,
+                                                nullptr, fold ? (char*)d->xn + (size_t)cls_row * C * esz : nullptr, rowC, s));
         }
     }
     return mhmr_launch_final_norm(d->resid, d->norm_w, d->norm_b, ctx16, ldctx, feat32, B, d->N, Tp, C, 1e-6f, dt, s);

@@ -256,6 +256,12 @@ int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s) {
     if (g.img_rows > 0 && (g.img_rows % BM || g.M % g.img_rows || g.img_stride < g.img_rows || g.epi == EPI_PATCH)) return MHMR_ERR_BAD_SHAPE;
     if (g.a_k > 0 && (g.a_k % BK || g.K != 2 * g.a_k || g.ldw < g.K)) return MHMR_ERR_BAD_SHAPE;
     if (g.epi == EPI_OP16_QK && g.N % 128) return MHMR_ERR_BAD_SHAPE;      // Q | K halves are whole 64-column blocks
+    if (g.x16 || g.pstats || g.rowstats) {       // LayerNorm fold: 256x256 kernel only
+        if (g_force_gemm128 || !mhmr_gemm256_eligible(g)) return MHMR_ERR_BAD_SHAPE;
+        if (g.rowstats && g.K < 256) return MHMR_ERR_BAD_SHAPE;      // (the strip DMA of a tile needs a barrier-separated k pair in front of it)
+        if (g.rowstats && (g.bias || !g.colsum || !g.fbias || !(g.epi == EPI_OP16_QK || g.epi == EPI_VT || g.epi == EPI_OP16_GELU))) return MHMR_ERR_BAD_ARG;
+        if ((g.x16 != nullptr) != (g.pstats != nullptr) || (g.x16 && g.epi != EPI_RESID)) return MHMR_ERR_BAD_ARG;
+    }
     prof_begin(PROF_GEMM, s);
     int rc;
     if (!g_force_gemm128 && mhmr_gemm256_eligible(g)) {

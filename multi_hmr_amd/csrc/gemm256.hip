@@ -52,6 +52,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     const int g4 = lane >> 4, l15 = lane & 15;   // 16x16x32 fragments: row/col = lane & 15, k-group / row-quad = lane >> 4
 
     constexpr bool ROWMAJOR = (EPI != EPI_VT);
+    constexpr bool FOLDABLE = (EPI == EPI_OP16_QK || EPI == EPI_VT || EPI == EPI_OP16_GELU);      // consumers of a folded LayerNorm
     // P = first MFMA operand (D rows, 4 consecutive per accumulator quad), Q = second (D columns, one per lane)
     const T* Pm = ROWMAJOR ? (const T*)g.W : (const T*)g.A;
     const T* Qm = ROWMAJOR ? (const T*)g.A : (const T*)g.W;
@@ -204,6 +205,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
             // the activation side (Q for row-major outputs, P for V^T) wraps around at nta k tiles (low-half weight pass)
             const int t1p = ROWMAJOR ? t1 : ka(t1), t2p = ROWMAJOR ? t2 : ka(t2), t3p = ROWMAJOR ? t3 : ka(t3);
             const int t2q = ROWMAJOR ? ka(t2) : t2, t3q = ROWMAJOR ? ka(t3) : t3;
+            if constexpr (FOLDABLE) {
+                // LayerNorm fold: this tile's column sums / folded bias (256 output columns) and row statistics (256 rows) travel by
+                // LDS-DMA into the first 4 KiB of the (idle) staging region while the last pair of k tiles is computed: 1 KiB per wave
+                // 0..3, sixteen ring copies younger than it by the end of the pair, so the phases' counted waits cover its landing
+                if (wrap && g.rowstats != nullptr && w < 4) {
+                    const int nbase = ROWMAJOR ? p0 : q0;
+                    const float* sp = w == 0 ? g.colsum + nbase : w == 1 ? g.fbias + nbase : g.rowstats + 2 * (size_t)ar + (w - 2) * 256;
+                    glds16(sp + lane * 4, smem + STAGE_OFF + w * 1024);
+                }
+            }
             // phase 1
             rdP(0, SLOT_P0);
             dma(p_src, p_lane, ldp, 1, t1p, BUF + SLOT_P1); MHMR_WAIT_DMA();
@@ -286,14 +297,72 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                 for (int it = 0; it < 4; ++it) {
                     const int row = 4 * it + (lane >> 4);
                     const f32x4 v = *(const f32x4*)(wl + row * 256 + ((c ^ row) * 16));
-                    *rptr(sidx, it) = r[sidx][it] + gm[h] * v;
+                    const f32x4 nv = r[sidx][it] + gm[h] * v;
+                    f32x4* rp = rptr(sidx, it);
+                    *rp = nv;
+                    if (g.x16 != nullptr) {
+                        // LayerNorm fold, producer side: the 16-bit copy of the new residual values (the next linear's A operand) and this
+                        // 64-column block's (sum, sum of squares) per row.  16 lanes (c = 0..15) hold one row's 64 columns.
+                        const uint32_t off = (uint32_t)((char*)rp - (char*)g.out);
+                        V4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (T)nv[e];
+                        *(V4*)((char*)g.x16 + (off >> 1)) = o;
+                        float s1 = (nv[0] + nv[1]) + (nv[2] + nv[3]);
+                        float s2 = (nv[0] * nv[0] + nv[1] * nv[1]) + (nv[2] * nv[2] + nv[3] * nv[3]);
+#pragma unroll
+                        for (int m = 1; m < 16; m <<= 1) {
+                            s1 += __shfl_xor(s1, m);
+                            s2 += __shfl_xor(s2, m);
+                        }
+                        if (c == 0) {
+                            const int prow = ar + 128 * j + 32 * wq + 16 * qs + row;
+                            const int slot = (p0 + 128 * h + 64 * wp) >> 6;
+                            *(f32x2*)(g.pstats + ((size_t)prow * (g.N >> 6) + slot) * 2) = (f32x2){s1, s2};
+                        }
+                    }
                 }
             }
         } else {
+        // LayerNorm fold, consumer side.  Row side = the activation rows (m), column side = the output columns (n).  Row values
+        // (rstd_m, t_m = -mean_m rstd_m) and column values (colsum_n, fbias_n) were DMA'd into smem + STAGE_OFF during the last k pair:
+        // [colsum 256 | fbias 256 | (mean, rstd) x 256 rows] floats.  A wave keeps the 128 + 64 positions it owns in six registers
+        // (lane L: P positions 128 h + 64 wp + L for h = 0 / 1, Q position 128 (L >> 5) + 32 wq + (L & 31)) and hands them to the lanes that
+        // need them through ds_bpermute; out = acc * rstd_m + t_m * colsum_n + fbias_n.
+        [[maybe_unused]] float fpa[2] = {0.f, 0.f}, fpb[2] = {0.f, 0.f}, fqa = 0.f, fqb = 0.f;      // P side (a, b) per h; Q side (a, b)
+        [[maybe_unused]] bool fold = false;
+        if constexpr (FOLDABLE) {
+            fold = g.rowstats != nullptr;
+            if (fold) {
+                const float* strip = (const float*)(smem + STAGE_OFF);
+                const int qpos = 128 * (lane >> 5) + 32 * wq + (lane & 31);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int ppos = 128 * h + 64 * wp + lane;
+                    if constexpr (ROWMAJOR) { fpa[h] = strip[ppos]; fpb[h] = strip[256 + ppos]; }                    // columns: colsum, fbias
+                    else { const f32x2 mr = *(const f32x2*)(strip + 512 + 2 * ppos); fpa[h] = mr[1]; fpb[h] = -mr[0] * mr[1]; }    // rows: rstd, t
+                }
+                if constexpr (ROWMAJOR) { const f32x2 mr = *(const f32x2*)(strip + 512 + 2 * qpos); fqa = mr[1]; fqb = -mr[0] * mr[1]; }
+                else { fqa = strip[qpos]; fqb = strip[256 + qpos]; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                MHMR_SYNC();                                  // every wave has its values: wave 0's staging area (the strip) may be overwritten
+            }
+        }
+        auto lane_get = [&](float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * src, __builtin_bit_cast(int, v))); };
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
+                [[maybe_unused]] float qa2[2] = {0.f, 0.f}, qb2[2] = {0.f, 0.f};
+                if constexpr (FOLDABLE) {
+                    if (fold) {
+#pragma unroll
+                        for (int qs = 0; qs < 2; ++qs) {
+                            qa2[qs] = lane_get(fqa, 32 * j + 16 * qs + l15);
+                            qb2[qs] = lane_get(fqb, 32 * j + 16 * qs + l15);
+                        }
+                    }
+                }
                 const int pb = p0 + 128 * h + 64 * wp;      // first P index of the block (n for row-major, LOGICAL token row for V^T)
                 const int qb = q0 + 128 * j + 32 * wq;      // first Q index (logical m for row-major, channel for V^T)
                 const int qphys = ar + 128 * j + 32 * wq;   // row-major outputs: physical row of qb
@@ -302,6 +371,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
 #pragma unroll
                     for (int ps = 0; ps < 4; ++ps) {
                         const int pc = 16 * ps + 4 * g4;    // lane owns P columns pc..pc+3 of Q rows 16*qs + l15
+                        [[maybe_unused]] f32x4 pa4 = {0.f, 0.f, 0.f, 0.f}, pb4 = {0.f, 0.f, 0.f, 0.f};      // P-side values of those four positions
+                        if constexpr (FOLDABLE) {
+                            if (fold) {              // (fetched where they are used: held per half they cost 32 registers the epilogue does not have)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    pa4[e] = lane_get(fpa[h], pc + e);
+                                    pb4[e] = lane_get(fpb[h], pc + e);
+                                }
+                            }
+                        }
                         const int gs = ((g4 & 1) << 1) | (g4 >> 1);
                         const int pos = ROWMAJOR ? pc : 16 * ps + 4 * gs;          // V^T: swap key bits 2 and 3
 #pragma unroll
@@ -311,6 +390,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 float v = acc[h][j][ps][qs][e];
+                                if constexpr (FOLDABLE) {
+                                    if (fold) {
+                                        if constexpr (ROWMAJOR) v = __builtin_fmaf(v, qa2[qs], __builtin_fmaf(qb2[qs], pa4[e], pb4[e]));   // rows = Q side
+                                        else v = __builtin_fmaf(v, pa4[e], __builtin_fmaf(pb4[e], qa2[qs], qb2[qs]));                      // rows = P side
+                                    }
+                                }
                                 if constexpr (EPI == EPI_OP16_GELU) v = gelu_fast(v);
                                 if constexpr (EPI == EPI_OP16_RELU) v = fmaxf(v, 0.f);
                                 if constexpr (EPI == EPI_OP16_QK) v *= qscale;

@@ -35,6 +35,17 @@ struct GemmArgs {
     // from the start, so acc = A . W_hi^T + A . W_lo^T in one accumulator chain.  0 = off.
     int a_k = 0;
     int colgroup = 0;        // gemm256: column-group tile order for wide outputs (set by mhmr_launch_gemm; MHMR_COLGROUP=0 disables)
+    // LayerNorm folded into the neighbouring GEMMs (gemm256 only): the LayerNorm pass of its own disappears.
+    //   producer (EPI_RESID): besides the fp32 residual rows it writes x16 = their 16-bit copy (RAW, un-normalised: the next linear's A
+    //   operand) and pstats[row][N / 64][2] = (sum, sum of squares) of every 64-column block of the row (summed over the row by
+    //   ln_stats_kernel -> rowstats[row] = (mean, rstd));
+    //   consumer (EPI_OP16_QK / EPI_VT / EPI_OP16_GELU with rowstats != null): W carries the LayerNorm weight (W' = W diag(w_ln)),
+    //   out = rstd_m * (acc - mean_m * colsum_n) + fbias_n,  colsum_n = sum_k W'[n][k],  fbias = b + W . b_ln;  `bias` must be null.
+    void* x16 = nullptr;
+    float* pstats = nullptr;
+    const float* rowstats = nullptr;
+    const float* colsum = nullptr;
+    const float* fbias = nullptr;
 };
 
 // physical row of logical activation row m (see GemmArgs::img_rows)

@@ -25,6 +25,10 @@ struct ClsArgs {
     void* out; long long o_stride;          // output row b at out + b * o_stride (elements of the output type)
     int n_base, C;                          // CLS_QKV: global column of local column 0; embed dim (column regions Q | K | V)
     void* vt; int H, Tp, vcol;              // CLS_QKV: V^T [B][H][64][Tp], the (already key-permuted) column of the class token
+    // LayerNorm fold (GemmArgs in mhmr_internal.h): consumer side -- rowstats (mean, rstd) of row b at rowstats + b * rs_stride floats,
+    // out = rstd * (acc - mean * colsum_n) + fbias_n (bias null); producer side (CLS_RESID) -- x16: 16-bit copy of the updated rows
+    const float* rowstats; long long rs_stride; const float* colsum; const float* fbias;
+    void* x16; long long x_stride;
 };
 
 enum { CLS_QKV = 0, CLS_RESID = 1, CLS_GELU = 2 };
@@ -71,17 +75,33 @@ __global__ __launch_bounds__(256) void cls_linear_kernel(const ClsArgs a) {
     for (int i = 0; i < 3; ++i) { acc0 += red[i][0][lane]; acc1 += red[i][1][lane]; }      // wave order: bit-reproducible
     // lane holds output columns n0 + 4 g4 + 0..3 of rows rb + l15 (acc0) and rb + 16 + l15 (acc1)
     const int nl = n0 + 4 * g4;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, cs = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) bv = *(const f32x4*)(a.bias + nl);
+    if (a.rowstats) { bv = *(const f32x4*)(a.fbias + nl); cs = *(const f32x4*)(a.colsum + nl); }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int m = rb + 16 * half + l15;
         if (m >= a.B) continue;
-        const f32x4 v = (half ? acc1 : acc0) + bv;
+        f32x4 v = half ? acc1 : acc0;
+        if (a.rowstats) {
+            const f32x2 mr = *(const f32x2*)(a.rowstats + (size_t)m * a.rs_stride);
+            const float t = -mr[0] * mr[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], mr[1], __builtin_fmaf(t, cs[e], bv[e]));
+        } else {
+            v += bv;
+        }
         if constexpr (EPI == CLS_RESID) {
             float* op = (float*)a.out + (size_t)m * a.o_stride + nl;
             const f32x4 gm = *(const f32x4*)(a.gamma + nl);
-            *(f32x4*)op = *(const f32x4*)op + gm * v;
+            const f32x4 nv = *(const f32x4*)op + gm * v;
+            *(f32x4*)op = nv;
+            if (a.x16) {
+                V4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (T)nv[e];
+                *(V4*)((T*)a.x16 + (size_t)m * a.x_stride + nl) = o;
+            }
         } else if constexpr (EPI == CLS_GELU) {
             V4 o;
 #pragma unroll
@@ -131,12 +151,22 @@ int launch_cls(const ClsArgs& a, int epi, hipStream_t s) {
 
 // epi: 0 = Q | K | V projection of the class rows (Q pre-scaled, V scattered into column `vcol` of V^T), 1 = out32 += gamma * (acc + bias),
 // 2 = out16 = gelu(acc + bias)
-int mhmr_launch_cls_linear(const void* A, long long a_stride, const void* W, int ldw, int B, int N, int K, int a_k, const float* bias,
-                           const float* gamma, void* out, long long o_stride, int n_base, int C, void* vt, int H, int Tp, int vcol, int epi,
-                           int dtype, hipStream_t s) {
+int mhmr_launch_cls_linear_fold(const void* A, long long a_stride, const void* W, int ldw, int B, int N, int K, int a_k, const float* bias,
+                                const float* gamma, void* out, long long o_stride, int n_base, int C, void* vt, int H, int Tp, int vcol, int epi,
+                                int dtype, const float* rowstats, long long rs_stride, const float* colsum, const float* fbias, void* x16,
+                                long long x_stride, hipStream_t s) {
     if (B <= 0 || N <= 0 || N % 16 || K <= 0 || K % 128 || ldw < K || (a_k > 0 && K != 2 * a_k) || a_stride % 8 || ldw % 8) return MHMR_ERR_BAD_SHAPE;
     if (epi == CLS_RESID && !gamma) return MHMR_ERR_BAD_ARG;
     if (epi == CLS_QKV && (C % 64 || n_base % 16 || !vt || Tp <= vcol)) return MHMR_ERR_BAD_SHAPE;
-    const ClsArgs a{A, a_stride, W, ldw, B, N, K, a_k, bias, gamma, out, o_stride, n_base, C, vt, H, Tp, vcol};
+    if (rowstats && (!colsum || !fbias || bias || epi == CLS_RESID)) return MHMR_ERR_BAD_ARG;
+    const ClsArgs a{A, a_stride, W, ldw, B, N, K, a_k, bias, gamma, out, o_stride, n_base, C, vt, H, Tp, vcol, rowstats, rs_stride, colsum, fbias,
+                    x16, x_stride};
     return dtype == MHMR_DT_F16 ? launch_cls<MHMR_DT_F16>(a, epi, s) : launch_cls<MHMR_DT_BF16>(a, epi, s);
+}
+
+int mhmr_launch_cls_linear(const void* A, long long a_stride, const void* W, int ldw, int B, int N, int K, int a_k, const float* bias,
+                           const float* gamma, void* out, long long o_stride, int n_base, int C, void* vt, int H, int Tp, int vcol, int epi,
+                           int dtype, hipStream_t s) {
+    return mhmr_launch_cls_linear_fold(A, a_stride, W, ldw, B, N, K, a_k, bias, gamma, out, o_stride, n_base, C, vt, H, Tp, vcol, epi, dtype,
+                                       nullptr, 0, nullptr, nullptr, nullptr, 0, s);
 }

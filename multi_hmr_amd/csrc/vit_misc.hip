@@ -105,6 +105,45 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// LayerNorm fold (GemmArgs::pstats): row statistics of the residual stream for the consumers of a folded LayerNorm.
+//   patch row (b, n):  (sum, sum of squares) of its nblk 64-column blocks, written by the residual epilogue of the producing GEMM, are
+//                      added in block order (bit-reproducible) -> mean, rstd = rsqrt(E[x^2] - mean^2 + eps)
+//   class row (b, N):  its residual row is updated by the skinny kernel (csrc/vit_cls.hip), which leaves no block sums: one wave reads
+//                      the fp32 row and takes the centred variance, like layernorm_kernel
+// rowstats[b * Tp + t] = (mean, rstd).  grid = ceil(B * N / 256) + ceil(B / 4) blocks of 256 threads.
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ pstats, const float* __restrict__ resid,
+                                                       float* __restrict__ rowstats, int B, int N, int Tp, int C, int nblk, float eps,
+                                                       int patch_blocks) {
+    if ((int)blockIdx.x < patch_blocks) {
+        const int m = blockIdx.x * 256 + threadIdx.x;
+        if (m >= B * N) return;
+        const int b = m / N, n = m - b * N;
+        const size_t row = (size_t)b * Tp + n;
+        const f32x4* ps = (const f32x4*)(pstats + row * nblk * 2);         // two blocks per 16-byte load
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = 0; i < nblk / 2; ++i) {
+            const f32x4 v = ps[i];
+            s1 += v[0]; s2 += v[1];
+            s1 += v[2]; s2 += v[3];
+        }
+        const float mean = s1 * (1.0f / C);
+        const float var = fmaxf(s2 * (1.0f / C) - mean * mean, 0.f);
+        *(f32x2*)(rowstats + row * 2) = (f32x2){mean, rsqrtf(var + eps)};
+    } else {
+        const int b = (blockIdx.x - patch_blocks) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (b >= B) return;
+        const size_t row = (size_t)b * Tp + N;
+        const float* ip = resid + row * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += ip[c];
+        const float mean = wave_sum(s) * (1.0f / C);
+        float q = 0.f;
+        for (int c = lane; c < C; c += 64) { const float d = ip[c] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + eps);
+        if (lane == 0) *(f32x2*)(rowstats + row * 2) = (f32x2){mean, rstd};
+    }
+}
+
 template <int DT, bool FINAL>
 int launch_ln(const float* in, const float* w, const float* b, void* out16, int ld16, float* out32, int rows, int C,
               int Np, int Tp, float eps, hipStream_t s) {
@@ -149,6 +188,15 @@ int mhmr_launch_layernorm(const float* in, const float* w, const float* b, void*
                           int dtype, hipStream_t s) {
     return dtype == MHMR_DT_F16 ? launch_ln<MHMR_DT_F16, false>(in, w, b, out16, C, nullptr, rows, C, 0, 0, eps, s)
                                 : launch_ln<MHMR_DT_BF16, false>(in, w, b, out16, C, nullptr, rows, C, 0, 0, eps, s);
+}
+
+int mhmr_launch_ln_stats(const float* pstats, const float* resid, float* rowstats, int B, int N, int Tp, int C, float eps, hipStream_t s) {
+    if (C % 128) return MHMR_ERR_BAD_SHAPE;
+    const int patch_blocks = (B * N + 255) / 256;
+    hipLaunchKernelGGL(ln_stats_kernel, dim3(patch_blocks + (B + 3) / 4), dim3(256), 0, s, pstats, resid, rowstats, B, N, Tp, C, C / 64, eps,
+                       patch_blocks);
+    MHMR_CHECK_LAUNCH();
+    return 0;
 }
 
 int mhmr_launch_final_norm(const float* resid, const float* w, const float* b, void* ctx16, int ldctx, float* feat32,

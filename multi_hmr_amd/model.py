@@ -242,6 +242,8 @@ class Model(nn.Module):
         # low-half weight passes of the V / output projections (vit.DEFAULT_WLO; "" = none): what puts every output within 1e-3
         self.wlo = kwargs.get("wlo", os.environ.get("MHMR_WLO"))
         vit.parse_wlo(vit.DEFAULT_WLO if self.wlo is None else self.wlo, 64)       # fail early on a malformed spec
+        # LayerNorm folded into the neighbouring GEMMs (None = wherever the shapes allow it: vit.fold_eligible)
+        self.lnfold = kwargs.get("lnfold")
         self.backbone = Dinov2Backbone(backbone, pretrained=pretrained_backbone, depth_override=kwargs.get("backbone_depth"))
         self.embed_dim, self.patch_size = self.backbone.embed_dim, self.backbone.patch_size
         assert self.img_size % self.patch_size == 0, "Invalid img size"
@@ -291,7 +293,7 @@ class Model(nn.Module):
 
     def _pack(self, device):
         self._ws.clear()
-        P = vit.pack_encoder(self.backbone.encoder, self.img_size, self.precision, device, self.wlo)
+        P = vit.pack_encoder(self.backbone.encoder, self.img_size, self.precision, device, self.wlo, self.lnfold)
         dt_id, tdt = P["dt_id"], P["tdt"]
         C, G, N = P["C"], P["G"], P["N"]
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()

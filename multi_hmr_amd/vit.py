@@ -43,7 +43,14 @@ def hi_lo(w: torch.Tensor, tdt) -> torch.Tensor:
     return torch.cat([hi, lo], dim=1).contiguous()
 
 
-def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = None) -> dict:
+def fold_eligible(C: int, N: int) -> bool:
+    """The LayerNorm fold (csrc/gemm256.hip, GemmArgs::pstats / rowstats) needs the token-row map: every block linear on the 256x256
+    kernel.  MHMR_LNFOLD=0 / MHMR_ROWMAP=0 switch it off (A/B measurements)."""
+    import os
+    return (os.environ.get("MHMR_LNFOLD", "1") != "0" and os.environ.get("MHMR_ROWMAP", "1") != "0" and C % 256 == 0 and N % 256 == 0)
+
+
+def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = None, lnfold: bool | None = None) -> dict:
     """DINOv2 encoder parameters (key names of torch.hub dinov2_vit*14) -> device tensors in the kernels' layouts.
 
     16-bit [N, K] linears (K contiguous = MFMA operand order), fp32 biases / LayerNorm / LayerScale, the pos-embed bicubically
@@ -70,15 +77,48 @@ def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = N
     blocks = (_lib.VitBlock * L)()
     lo_passes = parse_wlo(DEFAULT_WLO if wlo is None else wlo, L)
     P["wlo"] = {i: sorted(v) for i, v in lo_passes.items()}
+    # LayerNorm fold: norm2 -> fc1 in every block, norm1 -> qkv from block 1 on (block 0's norm1 follows the patch embedding, whose
+    # epilogue leaves no row statistics: it stays a LayerNorm pass).  A folded linear consumes the RAW 16-bit residual rows:
+    #   y = rstd (x16 . W'^T - mean colsum) + b',   W' = W diag(w_ln) (rounded to 16 bits AFTER the fold),  b' = b + W b_ln,
+    #   colsum[n] = sum_k W'[n][k] over exactly the 16-bit values the matrix pipe multiplies (hi + lo where there is a low half)
+    P["fold"] = fold_eligible(Cd, N) if lnfold is None else bool(lnfold)
+    if P["fold"] and not (Cd % 256 == 0 and N % 256 == 0):
+        raise ValueError("lnfold needs embed_dim and the patch count per image to be multiples of 256")
+
+    def folded(lin, norm, lo_rows=None):
+        """-> (op16 W' [N, K], fp32 b' [N], fp32 colsum [N], hi|lo of rows lo_rows or None)"""
+        W, lw, lb = f32(lin.weight).double(), f32(norm.weight).double(), f32(norm.bias).double()
+        Wf = (W * lw[None, :]).float()
+        bias = (f32(lin.bias).double() + W @ lb).float()
+        W16 = Wf.to(tdt)
+        colsum = W16.double().sum(1)
+        w2 = None
+        if lo_rows is not None:
+            w2 = hi_lo(Wf[lo_rows], tdt)
+            colsum[lo_rows] = w2.double().sum(1)
+        return W16.contiguous(), bias.contiguous(), colsum.float().contiguous(), w2
+
     for i, b in enumerate(enc.blocks):
         blk = blocks[i]
-        blk.v_w2 = k(hi_lo(f32(b.attn.qkv.weight)[2 * Cd:], tdt)) if "v" in lo_passes.get(i, ()) else None
+        f1, f2 = P["fold"] and i > 0, P["fold"]
+        v_rows = slice(2 * Cd, 3 * Cd)
+        blk.flags = (1 if f1 else 0) | (2 if f2 else 0)
         blk.proj_w2 = k(hi_lo(f32(b.attn.proj.weight), tdt)) if "proj" in lo_passes.get(i, ()) else None
         blk.ln1_w, blk.ln1_b = k(f32(b.norm1.weight)), k(f32(b.norm1.bias))
-        blk.qkv_w, blk.qkv_b = k(op(b.attn.qkv.weight)), k(f32(b.attn.qkv.bias))
+        if f1:
+            w16, bias, colsum, v2 = folded(b.attn.qkv, b.norm1, v_rows if "v" in lo_passes.get(i, ()) else None)
+            blk.qkv_w, blk.qkv_b, blk.qkv_colsum = k(w16), k(bias), k(colsum)
+            blk.v_w2 = k(v2) if v2 is not None else None
+        else:
+            blk.qkv_w, blk.qkv_b, blk.qkv_colsum = k(op(b.attn.qkv.weight)), k(f32(b.attn.qkv.bias)), None
+            blk.v_w2 = k(hi_lo(f32(b.attn.qkv.weight)[v_rows], tdt)) if "v" in lo_passes.get(i, ()) else None
         blk.proj_w, blk.proj_b, blk.ls1 = k(op(b.attn.proj.weight)), k(f32(b.attn.proj.bias)), k(f32(b.ls1.gamma))
         blk.ln2_w, blk.ln2_b = k(f32(b.norm2.weight)), k(f32(b.norm2.bias))
-        blk.fc1_w, blk.fc1_b = k(op(b.mlp.fc1.weight)), k(f32(b.mlp.fc1.bias))
+        if f2:
+            w16, bias, colsum, _ = folded(b.mlp.fc1, b.norm2)
+            blk.fc1_w, blk.fc1_b, blk.fc1_colsum = k(w16), k(bias), k(colsum)
+        else:
+            blk.fc1_w, blk.fc1_b, blk.fc1_colsum = k(op(b.mlp.fc1.weight)), k(f32(b.mlp.fc1.bias)), None
         blk.fc2_w, blk.fc2_b, blk.ls2 = k(op(b.mlp.fc2.weight)), k(f32(b.mlp.fc2.bias)), k(f32(b.ls2.gamma))
     P["vit"] = dict(blocks=blocks, patch_w=k(pw.to(tdt).contiguous()), patch_b=k(f32(enc.patch_embed.proj.bias)),
                     cls_pos0=k(cls_pos0.contiguous()), pos=k(pos.contiguous()), norm_w=k(f32(enc.norm.weight)),
@@ -130,9 +170,14 @@ class WorkspaceCache:
         Cd, N, Tp, H = P["C"], P["N"], padded_tokens(P, B), P["H"]
         Mp = roundup(B * N, 128)
         z = lambda *s, dtype=tdt: torch.zeros(*s, dtype=dtype, device=dev)
+        if P.get("fold") and not row_map(P, B):
+            raise _lib.MhmrError(f"batch {B} is too large for the token-row map this pack's folded LayerNorms need (32-bit residual offsets of "
+                                 "the 256x256 kernel); build the model with lnfold=False for such batches")
         ws = dict(a_patch=z(Mp, P["Kp"]), resid=z(B * Tp, Cd, dtype=torch.float32), xn=z(B * Tp, Cd), qk=z(B * Tp, 2 * Cd),
                   vt=z(B * H * 64, Tp), att=z(B * Tp, Cd), hid=z(B * Tp, 4 * Cd), feat32=z(B * N, Cd, dtype=torch.float32),
                   attn_flags=z(_lib.lib().mhmr_attention_flag_count(B, Tp, H), dtype=torch.int32))
+        if P.get("fold"):
+            ws.update(pstats=z(B * Tp, Cd // 64, 2, dtype=torch.float32), rowstats=z(B * Tp, 2, dtype=torch.float32))
         ws.update(extra(P, B, z))
         v = P["vit"]
         d = _lib.VitDesc()
@@ -143,6 +188,8 @@ class WorkspaceCache:
         d.norm_w, d.norm_b = v["norm_w"], v["norm_b"]
         for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid", "attn_flags"):
             setattr(d, n, ws[n].data_ptr())
+        d.pstats = ws["pstats"].data_ptr() if P.get("fold") else None
+        d.rowstats = ws["rowstats"].data_ptr() if P.get("fold") else None
         ws["vit_desc"], ws["Tp"] = d, Tp
         self._ws[key] = ws
         return ws

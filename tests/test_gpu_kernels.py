@@ -293,6 +293,78 @@ def test_cls_linear(L, name, dt, tdt, tol, B):
     assert maxrel(hid.view(B, Tp, 2 * C)[:, Ncls].float(), torch.nn.functional.gelu(rows @ W1.float().T + b1)) < tol
 
 
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+def test_layernorm_fold(L, name, dt, tdt, tol):
+    """LayerNorm folded into the neighbouring GEMMs (csrc/gemm256.hip): the residual epilogue leaves the 16-bit copy of the RAW residual
+    rows + per-block (sum, sum of squares); mhmr_ln_stats finishes (mean, rstd) per row (class rows from the fp32 row itself); the
+    consuming linears (GELU / Q|K / V^T epilogues) compute rstd (x16 . W'^T - mean colsum) + b' -- against torch's layer_norm + linear."""
+    B, Nimg, Tp, C = 3, 256, 320, 256
+    H, M = C // 64, B * Nimg
+    g = torch.Generator(device="cpu").manual_seed(17)
+    patch = torch.zeros(B, Tp, dtype=torch.bool)
+    patch[:, :Nimg] = True
+    patch = patch.reshape(-1).to(dev())
+    resid0 = (torch.randn(B * Tp, C, generator=g) * 2.0 + 0.3).to(dev())
+    att = torch.randn(B * Tp, C, generator=g).to(dev()).to(tdt)
+    Wp = (torch.randn(C, C, generator=g) / math.sqrt(C)).to(dev()).to(tdt)
+    bp, gamma = torch.randn(C, generator=g).to(dev()), torch.randn(C, generator=g).to(dev())
+    # ---- producer ----
+    out = resid0.clone()
+    x16 = torch.full((B * Tp, C), 7.0, dtype=tdt, device=dev())
+    pstats = torch.full((B * Tp, C // 64, 2), -1.0, device=dev())
+    _lib.check(L.mhmr_gemm16_ln(att.data_ptr(), C, Wp.data_ptr(), C, M, C, C, bp.data_ptr(), gamma.data_ptr(), out.data_ptr(), C, Tp, H,
+                                _lib.EPI_RESID, dt, Nimg, Tp, 0, x16.data_ptr(), pstats.data_ptr(), None, None, None, stream()), "resid + fold")
+    ref = resid0 + gamma * (att.float() @ Wp.float().T + bp)
+    assert maxrel(out[patch], ref[patch]) < 2e-5 and torch.equal(out[~patch], resid0[~patch])
+    assert torch.equal(x16[patch].float(), out[patch].to(tdt).float()) and torch.all(x16[~patch] == 7.0)
+    blocks = out.view(B * Tp, C // 64, 64)
+    assert maxrel(pstats[patch][..., 0], blocks.sum(-1)[patch]) < 1e-5 and maxrel(pstats[patch][..., 1], (blocks * blocks).sum(-1)[patch]) < 1e-5
+    assert torch.all(pstats[~patch] == -1.0)
+    # ---- row statistics (patch rows from the block sums, class rows = row Nimg of every image from the fp32 row) ----
+    rowstats = torch.full((B * Tp, 2), -1.0, device=dev())
+    _lib.check(L.mhmr_ln_stats(pstats.data_ptr(), out.data_ptr(), rowstats.data_ptr(), B, Nimg, Tp, C, 1e-6, stream()), "ln_stats")
+    mean = out.double().mean(-1)
+    rstd = 1.0 / torch.sqrt(out.double().var(-1, unbiased=False) + 1e-6)
+    has = patch.clone()
+    has.view(B, Tp)[:, Nimg] = True
+    assert maxrel(rowstats[has][:, 0], mean[has]) < 1e-5 and maxrel(rowstats[has][:, 1], rstd[has]) < 1e-5
+    assert torch.all(rowstats[~has] == -1.0)
+    # ---- consumers ----
+    ln_w, ln_b = (1.0 + 0.2 * torch.randn(C, generator=g)).to(dev()), (0.1 * torch.randn(C, generator=g)).to(dev())
+    xn_true = torch.nn.functional.layer_norm(out, (C,), ln_w, ln_b, 1e-6)
+    for epi, N in ((_lib.EPI_OP16_GELU, 512), (_lib.EPI_OP16_QK, 512), (_lib.EPI_VT, 256)):
+        W = (torch.randn(N, C, generator=g) / math.sqrt(C)).to(dev())
+        b = torch.randn(N, generator=g).to(dev())
+        Wf = (W * ln_w).to(tdt)
+        colsum = Wf.double().sum(1).float()
+        fb = (b.double() + W.double() @ ln_b.double()).float()
+        lin = rowstats[:, 1:2].double() * (x16.double() @ Wf.double().T - rowstats[:, 0:1].double() * colsum.double()) + fb.double()   # the kernel's formula
+        true = xn_true.double() @ W.double().T + b.double()                                                                        # what it stands for
+        if epi == _lib.EPI_VT:
+            vt = torch.full((B, N // 64, 64, Tp), 7.0, dtype=tdt, device=dev())
+            _lib.check(L.mhmr_gemm16_ln(x16.data_ptr(), C, Wf.data_ptr(), C, M, N, C, None, None, vt.data_ptr(), 0, Tp, N // 64, epi, dt, Nimg, Tp,
+                                        0, None, None, rowstats.data_ptr(), colsum.data_ptr(), fb.data_ptr(), stream()), "vt + fold")
+            perm = swap23(torch.arange(Nimg, device=dev()))
+            got = vt.float()[..., perm].permute(0, 3, 1, 2).reshape(B, Nimg, N)
+            want, wtrue = lin.view(B, Tp, N)[:, :Nimg], true.view(B, Tp, N)[:, :Nimg]
+            assert torch.all(vt[..., Nimg:] == 7.0)
+        else:
+            o16 = torch.full((B * Tp, N), 7.0, dtype=tdt, device=dev())
+            _lib.check(L.mhmr_gemm16_ln(x16.data_ptr(), C, Wf.data_ptr(), C, M, N, C, None, None, o16.data_ptr(), N, Tp, H, epi, dt, Nimg, Tp, 0,
+                                        None, None, rowstats.data_ptr(), colsum.data_ptr(), fb.data_ptr(), stream()), "consumer + fold")
+            assert torch.all(o16[~patch] == 7.0)
+            got = o16[patch].float()
+            want, wtrue = lin[patch], true[patch]
+            if epi == _lib.EPI_OP16_GELU:
+                want, wtrue = torch.nn.functional.gelu(want), torch.nn.functional.gelu(wtrue)
+            else:
+                sc = torch.ones(N, device=dev(), dtype=torch.float64)
+                sc[: N // 2] = _lib.ATTN_QSCALE
+                want, wtrue = want * sc, wtrue * sc
+        assert maxrel(got, want) < tol, (epi, maxrel(got, want))                 # same 16-bit operands: accumulation order + output rounding
+        assert rel(got, wtrue) < (2e-3 if name == "f16" else 1.6e-2), (epi, rel(got, wtrue))      # vs the real LayerNorm + linear
+
+
 # ------------------------------------------------------------------------------------------------------ attention
 def _attn_inputs(B, H, T, tdt, seed, qscale=1.0, pad=128):
     """q is handed over PRE-SCALED (include/mhmr.h: the Q half of qk holds q * MHMR_ATTN_QSCALE, scores are in the exp2 domain)."""
