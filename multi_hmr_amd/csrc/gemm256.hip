@@ -36,8 +36,22 @@ namespace {
 constexpr int HT = 16384;           // bytes per half-tile slot (128 rows x 128 B)
 constexpr int BUF = 4 * HT;         // one K-tile buffer: P0 | P1 | Q0 | Q1
 constexpr int SLOT_P0 = 0, SLOT_P1 = HT, SLOT_Q0 = 2 * HT, SLOT_Q1 = 3 * HT;
-constexpr int STAGE_OFF = 2 * BUF;  // 8 waves x 4 KiB epilogue staging
+constexpr int STAGE_OFF = 2 * BUF;  // 8 waves x 4 KiB epilogue staging (the LayerNorm-foldable epilogues: 8 x 2 KiB + the 4 KiB strip)
+constexpr int STRIP_OFF = STAGE_OFF + 8 * 2048;
 constexpr int LDS_BYTES = 2 * BUF + 8 * 4096;
+
+// sum over the 16 lanes of a DPP row, on the VALU (quad xor 1, quad xor 2, half-row mirror, row mirror); every lane ends with the sum
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);     // row_half_mirror
+    v += dpp_f32<0x140>(v);     // row_mirror
+    return v;
+}
 
 template <int DT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
@@ -207,12 +221,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
             const int t2q = ROWMAJOR ? ka(t2) : t2, t3q = ROWMAJOR ? ka(t3) : t3;
             if constexpr (FOLDABLE) {
                 // LayerNorm fold: this tile's column sums / folded bias (256 output columns) and row statistics (256 rows) travel by
-                // LDS-DMA into the first 4 KiB of the (idle) staging region while the last pair of k tiles is computed: 1 KiB per wave
-                // 0..3, sixteen ring copies younger than it by the end of the pair, so the phases' counted waits cover its landing
+                // LDS-DMA into the strip while the last pair of k tiles is computed: 1 KiB per wave 0..3, sixteen ring copies younger
+                // than it by the end of the pair, so the phases' counted waits cover its landing (and the barriers of the k loop
+                // separate it from the previous tile's epilogue, which read the strip: K >= 256, mhmr_launch_gemm)
                 if (wrap && g.rowstats != nullptr && w < 4) {
                     const int nbase = ROWMAJOR ? p0 : q0;
                     const float* sp = w == 0 ? g.colsum + nbase : w == 1 ? g.fbias + nbase : g.rowstats + 2 * (size_t)ar + (w - 2) * 256;
-                    glds16(sp + lane * 4, smem + STAGE_OFF + w * 1024);
+                    glds16(sp + lane * 4, smem + STRIP_OFF + w * 1024);
                 }
             }
             // phase 1
@@ -310,11 +325,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                         *(V4*)((char*)g.x16 + (off >> 1)) = o;
                         float s1 = (nv[0] + nv[1]) + (nv[2] + nv[3]);
                         float s2 = (nv[0] * nv[0] + nv[1] * nv[1]) + (nv[2] * nv[2] + nv[3] * nv[3]);
-#pragma unroll
-                        for (int m = 1; m < 16; m <<= 1) {
-                            s1 += __shfl_xor(s1, m);
-                            s2 += __shfl_xor(s2, m);
-                        }
+                        s1 = row16_sum(s1);
+                        s2 = row16_sum(s2);
                         if (c == 0) {
                             const int prow = ar + 128 * j + 32 * wq + 16 * qs + row;
                             const int slot = (p0 + 128 * h + 64 * wp) >> 6;
@@ -324,98 +336,89 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                 }
             }
         } else {
-        // LayerNorm fold, consumer side.  Row side = the activation rows (m), column side = the output columns (n).  Row values
-        // (rstd_m, t_m = -mean_m rstd_m) and column values (colsum_n, fbias_n) were DMA'd into smem + STAGE_OFF during the last k pair:
-        // [colsum 256 | fbias 256 | (mean, rstd) x 256 rows] floats.  A wave keeps the 128 + 64 positions it owns in six registers
-        // (lane L: P positions 128 h + 64 wp + L for h = 0 / 1, Q position 128 (L >> 5) + 32 wq + (L & 31)) and hands them to the lanes that
-        // need them through ds_bpermute; out = acc * rstd_m + t_m * colsum_n + fbias_n.
-        [[maybe_unused]] float fpa[2] = {0.f, 0.f}, fpb[2] = {0.f, 0.f}, fqa = 0.f, fqb = 0.f;      // P side (a, b) per h; Q side (a, b)
+        // LayerNorm fold, consumer side.  Row side = the activation rows (m), column side = the output columns (n).  The tile's column
+        // values (colsum_n, fbias_n) and row values (mean_m, rstd_m) were DMA'd into the strip (smem + STRIP_OFF) during the last k pair:
+        // [colsum 256 | fbias 256 | (mean, rstd) x 256 rows] floats;  out = acc * rstd_m + t_m * colsum_n + fbias_n,  t_m = -mean_m rstd_m.
+        // The foldable epilogues stage 16-row passes (2 KiB per wave instead of 4), which leaves the strip its own 4 KiB of LDS: it is
+        // read where it is used (a register-resident strip handed around by ds_bpermute cost 144 LDS-crossbar operations per tile and
+        // wave, and the residual epilogue's 16-lane sums as ds_bpermute chains another 256: together they ate the whole LayerNorm pass).
         [[maybe_unused]] bool fold = false;
-        if constexpr (FOLDABLE) {
-            fold = g.rowstats != nullptr;
-            if (fold) {
-                const float* strip = (const float*)(smem + STAGE_OFF);
-                const int qpos = 128 * (lane >> 5) + 32 * wq + (lane & 31);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int ppos = 128 * h + 64 * wp + lane;
-                    if constexpr (ROWMAJOR) { fpa[h] = strip[ppos]; fpb[h] = strip[256 + ppos]; }                    // columns: colsum, fbias
-                    else { const f32x2 mr = *(const f32x2*)(strip + 512 + 2 * ppos); fpa[h] = mr[1]; fpb[h] = -mr[0] * mr[1]; }    // rows: rstd, t
-                }
-                if constexpr (ROWMAJOR) { const f32x2 mr = *(const f32x2*)(strip + 512 + 2 * qpos); fqa = mr[1]; fqb = -mr[0] * mr[1]; }
-                else { fqa = strip[qpos]; fqb = strip[256 + qpos]; }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                MHMR_SYNC();                                  // every wave has its values: wave 0's staging area (the strip) may be overwritten
-            }
-        }
-        auto lane_get = [&](float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * src, __builtin_bit_cast(int, v))); };
+        if constexpr (FOLDABLE) fold = g.rowstats != nullptr;
+        [[maybe_unused]] const float* strip = (const float*)(smem + STRIP_OFF);
+        constexpr int NPASS = FOLDABLE ? 2 : 1;              // staging passes per (h, j): 16 or 32 Q rows
+        if constexpr (FOLDABLE) wl = smem + STAGE_OFF + w * 2048;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                [[maybe_unused]] float qa2[2] = {0.f, 0.f}, qb2[2] = {0.f, 0.f};
-                if constexpr (FOLDABLE) {
-                    if (fold) {
-#pragma unroll
-                        for (int qs = 0; qs < 2; ++qs) {
-                            qa2[qs] = lane_get(fqa, 32 * j + 16 * qs + l15);
-                            qb2[qs] = lane_get(fqb, 32 * j + 16 * qs + l15);
-                        }
-                    }
-                }
                 const int pb = p0 + 128 * h + 64 * wp;      // first P index of the block (n for row-major, LOGICAL token row for V^T)
                 const int qb = q0 + 128 * j + 32 * wq;      // first Q index (logical m for row-major, channel for V^T)
                 const int qphys = ar + 128 * j + 32 * wq;   // row-major outputs: physical row of qb
                 if constexpr (OUT16) {
                     const float qscale = (EPI == EPI_OP16_QK && pb < (g.N >> 1)) ? MHMR_ATTN_QSCALE : 1.f;   // 64 columns: all Q or all K
 #pragma unroll
-                    for (int ps = 0; ps < 4; ++ps) {
-                        const int pc = 16 * ps + 4 * g4;    // lane owns P columns pc..pc+3 of Q rows 16*qs + l15
-                        [[maybe_unused]] f32x4 pa4 = {0.f, 0.f, 0.f, 0.f}, pb4 = {0.f, 0.f, 0.f, 0.f};      // P-side values of those four positions
+                    for (int qh = 0; qh < NPASS; ++qh) {
+                        // Q-side values of this pass's rows (fold): one position per lane and qs
+                        [[maybe_unused]] float qa2[2] = {0.f, 0.f}, qb2[2] = {0.f, 0.f};
                         if constexpr (FOLDABLE) {
-                            if (fold) {              // (fetched where they are used: held per half they cost 32 registers the epilogue does not have)
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    pa4[e] = lane_get(fpa[h], pc + e);
-                                    pb4[e] = lane_get(fpb[h], pc + e);
-                                }
+                            if (fold) {
+                                const int qpos = 128 * j + 32 * wq + 16 * qh + l15;
+                                if constexpr (ROWMAJOR) { const f32x2 mr = *(const f32x2*)(strip + 512 + 2 * qpos); qa2[qh] = mr[1]; qb2[qh] = -mr[0] * mr[1]; }
+                                else { qa2[qh] = strip[qpos]; qb2[qh] = strip[256 + qpos]; }
                             }
                         }
-                        const int gs = ((g4 & 1) << 1) | (g4 >> 1);
-                        const int pos = ROWMAJOR ? pc : 16 * ps + 4 * gs;          // V^T: swap key bits 2 and 3
 #pragma unroll
-                        for (int qs = 0; qs < 2; ++qs) {
-                            const int qr = 16 * qs + l15;
-                            V4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float v = acc[h][j][ps][qs][e];
-                                if constexpr (FOLDABLE) {
-                                    if (fold) {
-                                        if constexpr (ROWMAJOR) v = __builtin_fmaf(v, qa2[qs], __builtin_fmaf(qb2[qs], pa4[e], pb4[e]));   // rows = Q side
-                                        else v = __builtin_fmaf(v, pa4[e], __builtin_fmaf(pb4[e], qa2[qs], qb2[qs]));                      // rows = P side
+                        for (int ps = 0; ps < 4; ++ps) {
+                            const int pc = 16 * ps + 4 * g4;    // lane owns P columns pc..pc+3 of Q rows 16*qs + l15
+                            [[maybe_unused]] f32x4 pa4 = {0.f, 0.f, 0.f, 0.f}, pb4 = {0.f, 0.f, 0.f, 0.f};      // P-side values of those four positions
+                            if constexpr (FOLDABLE) {
+                                if (fold) {
+                                    const int ppos = 128 * h + 64 * wp + pc;
+                                    if constexpr (ROWMAJOR) { pa4 = *(const f32x4*)(strip + ppos); pb4 = *(const f32x4*)(strip + 256 + ppos); }     // colsum, fbias
+                                    else {
+                                        const f32x4 m0 = *(const f32x4*)(strip + 512 + 2 * ppos), m1 = *(const f32x4*)(strip + 512 + 2 * ppos + 4);     // (mean, rstd) x 4 rows
+                                        pa4 = (f32x4){m0[1], m0[3], m1[1], m1[3]};
+                                        pb4 = (f32x4){-m0[0] * m0[1], -m0[2] * m0[3], -m1[0] * m1[1], -m1[2] * m1[3]};
                                     }
                                 }
-                                if constexpr (EPI == EPI_OP16_GELU) v = gelu_fast(v);
-                                if constexpr (EPI == EPI_OP16_RELU) v = fmaxf(v, 0.f);
-                                if constexpr (EPI == EPI_OP16_QK) v *= qscale;
-                                o[e] = (T)v;
                             }
-                            *(V4*)(wl + qr * 128 + (((pos >> 2) ^ ((qr & 7) << 1)) * 8)) = o;
-                        }
-                    }
-                    acc_init(h, j, 0, p0n, q0n);
-                    acc_init(h, j, 1, p0n, q0n);
+                            const int gs = ((g4 & 1) << 1) | (g4 >> 1);
+                            const int pos = ROWMAJOR ? pc : 16 * ps + 4 * gs;          // V^T: swap key bits 2 and 3
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        const int row = 8 * it + (lane >> 3), c16 = lane & 7;
-                        const u32x4 v = *(const u32x4*)(wl + row * 128 + ((c16 ^ (row & 7)) * 16));
-                        if constexpr (ROWMAJOR) {
-                            *(u32x4*)((T*)g.out + (size_t)(qphys + row) * g.ldo + pb + c16 * 8) = v;
-                        } else {
-                            // image and token-in-image of the block's first (logical) token row
-                            const int n = qb + row, bi = g.img_rows > 0 ? bimg : pb / g.Tp, tl = pb - bi * (g.img_rows > 0 ? g.img_rows : g.Tp);
-                            *(u32x4*)((T*)g.out + ((size_t)(bi * g.H + (n >> 6)) * 64 + (n & 63)) * g.Tp + tl + c16 * 8) = v;
+                            for (int qs = FOLDABLE ? qh : 0; qs < (FOLDABLE ? qh + 1 : 2); ++qs) {
+                                const int qr = FOLDABLE ? l15 : 16 * qs + l15;          // row of the staging image
+                                V4 o;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    float v = acc[h][j][ps][qs][e];
+                                    if constexpr (FOLDABLE) {
+                                        if (fold) {
+                                            if constexpr (ROWMAJOR) v = __builtin_fmaf(v, qa2[qs], __builtin_fmaf(qb2[qs], pa4[e], pb4[e]));   // rows = Q side
+                                            else v = __builtin_fmaf(v, pa4[e], __builtin_fmaf(pb4[e], qa2[qs], qb2[qs]));                      // rows = P side
+                                        }
+                                    }
+                                    if constexpr (EPI == EPI_OP16_GELU) v = gelu_fast(v);
+                                    if constexpr (EPI == EPI_OP16_RELU) v = fmaxf(v, 0.f);
+                                    if constexpr (EPI == EPI_OP16_QK) v *= qscale;
+                                    o[e] = (T)v;
+                                }
+                                *(V4*)(wl + qr * 128 + (((pos >> 2) ^ ((qr & 7) << 1)) * 8)) = o;
+                            }
+                        }
+                        if constexpr (FOLDABLE) acc_init(h, j, qh, p0n, q0n);
+                        else { acc_init(h, j, 0, p0n, q0n); acc_init(h, j, 1, p0n, q0n); }
+#pragma unroll
+                        for (int it = 0; it < (FOLDABLE ? 2 : 4); ++it) {
+                            const int srow = 8 * it + (lane >> 3), c16 = lane & 7;      // row of the staging image
+                            const int row = (FOLDABLE ? 16 * qh : 0) + srow;            // Q row of the (h, j) block
+                            const u32x4 v = *(const u32x4*)(wl + srow * 128 + ((c16 ^ (srow & 7)) * 16));
+                            if constexpr (ROWMAJOR) {
+                                *(u32x4*)((T*)g.out + (size_t)(qphys + row) * g.ldo + pb + c16 * 8) = v;
+                            } else {
+                                // image and token-in-image of the block's first (logical) token row
+                                const int n = qb + row, bi = g.img_rows > 0 ? bimg : pb / g.Tp, tl = pb - bi * (g.img_rows > 0 ? g.img_rows : g.Tp);
+                                *(u32x4*)((T*)g.out + ((size_t)(bi * g.H + (n >> 6)) * 64 + (n & 63)) * g.Tp + tl + c16 * 8) = v;
+                            }
                         }
                     }
                 } else {

@@ -17,6 +17,9 @@ for k, v in sorted(d.items()):
     if k.endswith("/f16"):
         print(k, "backbone %.2e" % v["backbone_rel_l2"], " ".join(f"{a}={b:.2e}" for a, b in v["rel_l2"].items() if a in ("scores", "offset", "shape", "expression", "rotmat", "transl", "v3d")))
 PY
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/trace -o headline --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --only-headline-kernels > $OUT/trace_headline.json 2> $OUT/trace_err.txt)
+find $OUT/trace -name "*kernel_trace.csv" -delete
+head -14 $(find $OUT/trace -name "*kernel_stats.csv" | head -1) | cut -c1-160 >> $OUT/summary.txt
 i=0
 for cfg in "X=1" "MHMR_LNFOLD=0" "X=2" "MHMR_LNFOLD=0"; do
   i=$((i+1))
