@@ -53,7 +53,9 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-template <int DT, int EPI>
+// FOLD: a consumer of a folded LayerNorm (GemmArgs::rowstats; EPI_OP16_QK / EPI_VT / EPI_OP16_GELU only) -- a kernel of its own, so that
+// the plain epilogues keep their 32-row staging passes and carry no run-time switches
+template <int DT, int EPI, bool FOLD = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
@@ -66,7 +68,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     const int g4 = lane >> 4, l15 = lane & 15;   // 16x16x32 fragments: row/col = lane & 15, k-group / row-quad = lane >> 4
 
     constexpr bool ROWMAJOR = (EPI != EPI_VT);
-    constexpr bool FOLDABLE = (EPI == EPI_OP16_QK || EPI == EPI_VT || EPI == EPI_OP16_GELU);      // consumers of a folded LayerNorm
+    constexpr bool FOLDABLE = FOLD;
+    static_assert(!FOLD || EPI == EPI_OP16_QK || EPI == EPI_VT || EPI == EPI_OP16_GELU, "consumers of a folded LayerNorm");
     // P = first MFMA operand (D rows, 4 consecutive per accumulator quad), Q = second (D columns, one per lane)
     const T* Pm = ROWMAJOR ? (const T*)g.W : (const T*)g.A;
     const T* Qm = ROWMAJOR ? (const T*)g.A : (const T*)g.W;
@@ -224,10 +227,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                 // LDS-DMA into the strip while the last pair of k tiles is computed: 1 KiB per wave 0..3, sixteen ring copies younger
                 // than it by the end of the pair, so the phases' counted waits cover its landing (and the barriers of the k loop
                 // separate it from the previous tile's epilogue, which read the strip: K >= 256, mhmr_launch_gemm)
-                if (wrap && g.rowstats != nullptr && w < 4) {
+                if (wrap && w < 4) {
                     const int nbase = ROWMAJOR ? p0 : q0;
                     const float* sp = w == 0 ? g.colsum + nbase : w == 1 ? g.fbias + nbase : g.rowstats + 2 * (size_t)ar + (w - 2) * 256;
-                    glds16(sp + lane * 4, smem + STRIP_OFF + w * 1024);
+                    // (the lane index is recomputed here: a register kept live across the k loop for it was spilled, and the reload's
+                    // vmcnt(0) drained the DMA ring once per tile)
+                    const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                    glds16(sp + ln * 4, smem + STRIP_OFF + w * 1024);
                 }
             }
             // phase 1
@@ -342,8 +348,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         // The foldable epilogues stage 16-row passes (2 KiB per wave instead of 4), which leaves the strip its own 4 KiB of LDS: it is
         // read where it is used (a register-resident strip handed around by ds_bpermute cost 144 LDS-crossbar operations per tile and
         // wave, and the residual epilogue's 16-lane sums as ds_bpermute chains another 256: together they ate the whole LayerNorm pass).
-        [[maybe_unused]] bool fold = false;
-        if constexpr (FOLDABLE) fold = g.rowstats != nullptr;
+        constexpr bool fold = FOLD;
         [[maybe_unused]] const float* strip = (const float*)(smem + STRIP_OFF);
         constexpr int NPASS = FOLDABLE ? 2 : 1;              // staging passes per (h, j): 16 or 32 Q rows
         if constexpr (FOLDABLE) wl = smem + STAGE_OFF + w * 2048;
@@ -471,16 +476,27 @@ int launch256_dt(const GemmArgs& g, hipStream_t s) {
         ncu = prop.multiProcessorCount;
     }
     const int grid = ntiles < ncu ? ntiles : ncu;      // one persistent block per CU
-#define MHMR_GEMM_CASE(E)                                                                                      \
-    case E: {                                                                                                  \
+#define MHMR_GEMM_LAUNCH(E, F)                                                                                 \
+    {                                                                                                          \
         static bool attr_set = false;                                                                          \
         if (!attr_set) {                                                                                       \
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<DT, E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<DT, E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       LDS_BYTES);                                                              \
             attr_set = true;                                                                                   \
         }                                                                                                      \
-        hipLaunchKernelGGL((gemm256_kernel<DT, E>), dim3(grid), dim3(512), LDS_BYTES, s, g);                   \
-        break;                                                                                                 \
+        hipLaunchKernelGGL((gemm256_kernel<DT, E, F>), dim3(grid), dim3(512), LDS_BYTES, s, g);                \
+    }
+#define MHMR_GEMM_CASE(E) \
+    case E: MHMR_GEMM_LAUNCH(E, false) break;
+    if (g.rowstats != nullptr) {            // consumers of a folded LayerNorm
+        switch (g.epi) {
+            case EPI_OP16_GELU: MHMR_GEMM_LAUNCH(EPI_OP16_GELU, true) break;
+            case EPI_VT: MHMR_GEMM_LAUNCH(EPI_VT, true) break;
+            case EPI_OP16_QK: MHMR_GEMM_LAUNCH(EPI_OP16_QK, true) break;
+            default: return MHMR_ERR_BAD_ARG;
+        }
+        MHMR_CHECK_LAUNCH();
+        return 0;
     }
     switch (g.epi) {
         MHMR_GEMM_CASE(EPI_OP16)
@@ -495,6 +511,7 @@ int launch256_dt(const GemmArgs& g, hipStream_t s) {
             return MHMR_ERR_BAD_ARG;
     }
 #undef MHMR_GEMM_CASE
+#undef MHMR_GEMM_LAUNCH
     MHMR_CHECK_LAUNCH();
     return 0;
 }

@@ -6,8 +6,8 @@
 // paid as 9 / 17 / 33 -- and the B class rows (one per image, Tp rows apart) are computed here: a "skinny" GEMM, M = B <= 32 rows per
 // block pass, which is a weight-streaming problem (2 ... 8 MB of 16-bit weights per linear against 67 ... 268 MFLOP).
 //
-//   grid = (N / 16, ceil(B / 32)); one workgroup = 4 waves = 16 output columns x 32 rows; the k range is split over the four waves
-//   (each streams a quarter of the 16 weight rows straight into MFMA operand registers: lane (n = lane & 15, k group = lane >> 4)
+//   grid = (N / 16, ceil(B / 32)); one workgroup = NW = 8 (4 when K % 256 != 0) waves = 16 output columns x 32 rows; the k range is split
+//   over the waves (each streams its share of the 16 weight rows straight into MFMA operand registers: lane (n = lane & 15, k group = lane >> 4)
 //   holds W[n][32 s + 8 g .. + 7] as one 16-byte load; the activations' fragments come the same way, L2-resident), partial
 //   accumulators meet in LDS and are summed in wave order (bit-reproducible).  v_mfma_f32_16x16x32 with the WEIGHT as the first
 //   operand: a lane ends up with 4 consecutive output columns of one row -- the same orientation as gemm256.hip, so the epilogues
@@ -35,12 +35,12 @@ enum { CLS_QKV = 0, CLS_RESID = 1, CLS_GELU = 2 };
 
 // U = k steps (of 32) per batch of loads: a wave requests 3 U fragments (weight + two row blocks) before the first MFMA of the batch, so
 // a batch costs ONE L2 round trip (hipcc does not unroll the run-time k loop by itself: one round trip per k step, 32 in a row for fc2)
-template <int DT, int EPI, int U>
-__global__ __launch_bounds__(256) void cls_linear_kernel(const ClsArgs a) {
+template <int DT, int EPI, int U, int NW>
+__global__ __launch_bounds__(64 * NW) void cls_linear_kernel(const ClsArgs a) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
     typedef typename Op<DT>::V4 V4;
-    __shared__ f32x4 red[3][2][64];                       // partial accumulators of waves 1..3
+    __shared__ f32x4 red[NW - 1][2][64];                  // partial accumulators of waves 1..NW-1
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g4 = lane >> 4, l15 = lane & 15;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void cls_linear_kernel(const ClsArgs a) {
     const T* wp = (const T*)a.W + (size_t)(n0 + l15) * a.ldw + 8 * g4;
     const T* a0p = (const T*)a.A + (size_t)r0 * a.a_stride + 8 * g4;
     const T* a1p = (const T*)a.A + (size_t)r1 * a.a_stride + 8 * g4;
-    const int kq = a.K >> 2, k0 = w * kq;
+    const int kq = a.K / NW, k0 = w * kq;
     const int awrap = a.a_k > 0 ? a.a_k : a.K;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     for (int kk = k0; kk < k0 + kq; kk += 32 * U) {          // (a batch never straddles the wrap point: a_k % (32 U) == 0, launcher)
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void cls_linear_kernel(const ClsArgs a) {
     __syncthreads();
     if (w > 0) return;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { acc0 += red[i][0][lane]; acc1 += red[i][1][lane]; }      // wave order: bit-reproducible
+    for (int i = 0; i < NW - 1; ++i) { acc0 += red[i][0][lane]; acc1 += red[i][1][lane]; }      // wave order: bit-reproducible
     // lane holds output columns n0 + 4 g4 + 0..3 of rows rb + l15 (acc0) and rb + 16 + l15 (acc1)
     const int nl = n0 + 4 * g4;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f}, cs = {0.f, 0.f, 0.f, 0.f};
@@ -125,26 +125,34 @@ __global__ __launch_bounds__(256) void cls_linear_kernel(const ClsArgs a) {
     }
 }
 
-template <int DT, int U>
+template <int DT, int U, int NW>
 int launch_cls_u(const ClsArgs& a, int epi, hipStream_t s) {
     const dim3 grid(a.N / 16, (a.B + 31) / 32);
     switch (epi) {
-        case CLS_QKV: hipLaunchKernelGGL((cls_linear_kernel<DT, CLS_QKV, U>), grid, dim3(256), 0, s, a); break;
-        case CLS_RESID: hipLaunchKernelGGL((cls_linear_kernel<DT, CLS_RESID, U>), grid, dim3(256), 0, s, a); break;
-        case CLS_GELU: hipLaunchKernelGGL((cls_linear_kernel<DT, CLS_GELU, U>), grid, dim3(256), 0, s, a); break;
+        case CLS_QKV: hipLaunchKernelGGL((cls_linear_kernel<DT, CLS_QKV, U, NW>), grid, dim3(64 * NW), 0, s, a); break;
+        case CLS_RESID: hipLaunchKernelGGL((cls_linear_kernel<DT, CLS_RESID, U, NW>), grid, dim3(64 * NW), 0, s, a); break;
+        case CLS_GELU: hipLaunchKernelGGL((cls_linear_kernel<DT, CLS_GELU, U, NW>), grid, dim3(64 * NW), 0, s, a); break;
         default: return MHMR_ERR_BAD_ARG;
     }
     MHMR_CHECK_LAUNCH();
     return 0;
 }
 
+template <int DT, int NW>
+int launch_cls_nw(const ClsArgs& a, int epi, hipStream_t s) {
+    // the largest batch of k steps that divides a wave's k share and the wrap point
+    const int kq = a.K / NW, wrap = a.a_k > 0 ? a.a_k : kq;
+    auto ok = [&](int u) { return kq % (32 * u) == 0 && wrap % (32 * u) == 0; };
+    if (ok(8)) return launch_cls_u<DT, 8, NW>(a, epi, s);
+    if (ok(6)) return launch_cls_u<DT, 6, NW>(a, epi, s);
+    if (ok(4)) return launch_cls_u<DT, 4, NW>(a, epi, s);
+    if (ok(3)) return launch_cls_u<DT, 3, NW>(a, epi, s);
+    return launch_cls_u<DT, 1, NW>(a, epi, s);
+}
+
 template <int DT>
 int launch_cls(const ClsArgs& a, int epi, hipStream_t s) {
-    // the largest batch that divides a wave's k quarter and the wrap point: 8 steps (C = 1024), 6 (C = 768), else one step at a time
-    const int kq = a.K / 4, wrap = a.a_k > 0 ? a.a_k : kq;
-    if (kq % 256 == 0 && wrap % 256 == 0) return launch_cls_u<DT, 8>(a, epi, s);
-    if (kq % 192 == 0 && wrap % 192 == 0) return launch_cls_u<DT, 6>(a, epi, s);
-    return launch_cls_u<DT, 1>(a, epi, s);
+    return a.K % 256 == 0 ? launch_cls_nw<DT, 8>(a, epi, s) : launch_cls_nw<DT, 4>(a, epi, s);
 }
 
 }  // namespace
