@@ -254,7 +254,8 @@ int mhmr_layernorm_f32(const float* in, const float* w, const float* b, float* o
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct {
     int V, Vp;            /* 10475, V rounded up to a multiple of 48 (the vertex kernel's tile)               */
-    int Kb;               /* 486 + nb + 10 rounded up to a multiple of 32 (width of the feature rows F)        */
+    int Kb;               /* 486 + nb + 10 rounded up to a multiple of 32 (width of the feature rows F); the vertex kernel is built for
+                             Kb == 512, i.e. num_betas <= 16 (MHMR_ERR_BAD_SHAPE otherwise)                     */
     int nb, Kinf;         /* num_betas, max skinning influences per vertex                                   */
     int center_joint;     /* JOINT_NAMES.index(person_center) = 15 ('head'); < 0 = person_center None: nothing is
                              recentred and the pelvis is added to the translation (smpl_layer.py:128-130)       */

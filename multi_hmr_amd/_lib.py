@@ -32,7 +32,7 @@ class MhmrError(RuntimeError):
 #: swizzles; that build returned, for about one (person, 16-vertex tile) pair in 10^4, a projection computed with a ZERO focal length
 #: (the y row of K: the other 15 pairs of the same wave were right; deterministic per build, tools/debug_lbs.py).  Scalar f32 code is
 #: also what the guide recommends beside MFMAs (MI355X_MICROARCH.md: packed f32 VALU is an anti-lever there).
-EXTRA_FLAGS = {"lbs.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"lbs.hip": ["-fno-slp-vectorize", "-DMHMR_NO_SLP"]}
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

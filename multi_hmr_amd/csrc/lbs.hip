@@ -26,6 +26,16 @@
 #include "mhmr_common.h"
 #include "mhmr_internal.h"
 
+// This file must be compiled with -fno-slp-vectorize (multi_hmr_amd/_lib.py EXTRA_FLAGS passes -DMHMR_NO_SLP beside it): hipcc's SLP
+// vectoriser packs the per-vertex projection epilogue into v_pk_*_f32 with op_sel operand swizzles, and that build returned a
+// projection computed with a zero focal length for about one (person, vertex tile) pair in 10^4 (tests/test_gpu_kernels.py::
+// test_lbs_max_abs_gate_160_persons_x_20_seeds is the gate).  The packed and the scalar instruction streams were compared line by line
+// (round 3): the operand selection of the packed form is arithmetically right, no wait state is missing by the ISA manual's table, so
+// the cause is unresolved; scalar f32 is also what the guide recommends beside MFMAs.  Any other build recipe fails HERE, not at run time.
+#ifndef MHMR_NO_SLP
+#error "csrc/lbs.hip: build with -fno-slp-vectorize -DMHMR_NO_SLP (see the comment above)"
+#endif
+
 namespace {
 
 constexpr int NJ = 55;
@@ -585,11 +595,10 @@ extern "C" int mhmr_lbs_forward(const mhmr_lbs_consts* c, const float* rotvec, c
     if (c->Vp % LBS_TV || c->Vp < c->V || c->Kb != LBS_KB || c->Kb < 486 + c->nb + 10 || !c->skin16) return MHMR_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int Pp = (P + 15) / 16 * 16;
-    static bool lds_ok = false;                                       // 126 KB of dynamic LDS: above the default per-kernel limit
-    if (!lds_ok) {
+    {   // 126 KB of dynamic LDS: above the default per-kernel limit.  The attribute is per DEVICE: set it on every call (cheap) rather
+        // than remember a process-wide flag that is wrong for the second GPU of a process
         hipError_t e = hipFuncSetAttribute((const void*)lbs_vertex_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LBS_LDS);
         if (e != hipSuccess) return (int)e;
-        lds_ok = true;
     }
     hipLaunchKernelGGL(lbs_pose_kernel, dim3(Pp), dim3(64), 0, s, *c, rotvec, betas, expr, loc, dist, Kmat, det_b, P, Pp,
                        (_Float16*)ws_F, (_Float16*)ws_A, ws_xf, j3d, j2d, transl);

@@ -29,6 +29,9 @@ CASES = {
     "vitb_224_train": dict(backbone="dinov2_vitb14", img_size=224, depth_override=4, batch=2, persons=[1, 2], seed=4),
     "vits_448_infer": dict(backbone="dinov2_vits14", img_size=448, depth_override=2, batch=3, persons=None, seed=3,
                            nms_kernel_size=3, target_detections=5),
+    # inference mode (NMS, threshold, detection order) through the FULL-depth ViT-L (the released checkpoints' backbone)
+    "vitl_448_infer": dict(backbone="dinov2_vitl14", img_size=448, depth_override=None, batch=2, persons=None, seed=5,
+                           nms_kernel_size=3, target_detections=6, vstride=4),
     # BASELINE.json configurations at their full resolution and depth (one or two images: the reference on CPU needs minutes).
     # ``vstride`` keeps the files small: v3d / v2d are stored for every vstride-th vertex, everything else in full.
     "vits_672_full": dict(backbone="dinov2_vits14", img_size=672, depth_override=None, batch=2, persons=[8, 5], seed=21, vstride=4),
@@ -106,8 +109,10 @@ def main():
                     humans = model(x, K=K, is_training=False, det_thresh=det_thresh, nms_kernel_size=cfg["nms_kernel_size"])
                     out["det_thresh"] = np.float32(det_thresh)
                     out["num_humans"] = np.int64(len(humans))
+                    vs = cfg.get("vstride", 1)
                     for k in humans[0].keys():
-                        out["h_" + k] = torch.stack([h[k] for h in humans]).numpy()
+                        v = torch.stack([h[k] for h in humans])
+                        out["h_" + k] = (v[:, ::vs] if (vs > 1 and k == "v3d") else v).numpy()
                     # min distance of any (post-NMS) score from the threshold, for information
                     sc, _, _ = model.detection(z, cfg["nms_kernel_size"], det_thresh, z.shape[1])
                     out["score_margin"] = np.float32((sc - det_thresh).abs().min())

@@ -619,6 +619,43 @@ def test_lbs_against_oracle(L, smplx_data, P, center):
     assert float((j3d[:, [0]].cpu() - ref["transl_pelvis"]).abs().max()) < 2e-5
 
 
+def test_lbs_max_abs_gate_160_persons_x_20_seeds(L, smplx_data):
+    """The SLP-packed build of the vertex kernel's epilogue once returned, for about one (person, vertex tile) pair in 10^4, a projection
+    computed with a zero focal length (csrc/lbs.hip is built with -fno-slp-vectorize, enforced by a compile-time check in the source).
+    A relative-L2 comparison barely notices one 500-pixel outlier among 10^6 values: this gate is MAX-ABS over 160 persons x 20 seeds
+    (3200 persons x 10475 vertices = 7 x 10^5 (person, tile) pairs) for v3d AND v2d."""
+    import ctypes as C
+    from oracle import smplx_ref
+    from oracle.multihmr_ref import smpl_layer_forward
+    pk = packing.pack_smplx(smplx_data, 10, dev(), 15)
+    cs = packing.lbs_consts_struct(pk)
+    bm = smplx_ref.SMPLX(smplx_data, num_betas=10)
+    P, B, V = 160, 8, pk["V"]
+    d = lambda t, dt=torch.float32: t.to(device=dev(), dtype=dt).contiguous()
+    f = lambda *s: torch.zeros(*s, device=dev())
+    v3d, v2d, j3d, j2d, transl = f(P, V, 3), f(P, V, 2), f(P, 127, 3), f(P, 127, 2), f(P, 3)
+    wsF, wsA, wsX = f(packing.roundup(P, 16), pk["Kb"]), f(packing.roundup(P, 16), 768), f(P, 24)
+    worst3, worst2 = 0.0, 0.0
+    for seed in range(20):
+        g = torch.Generator(device="cpu").manual_seed(1000 + seed)
+        pose = 0.35 * torch.randn(P, 53, 3, generator=g)
+        shape, expr = torch.randn(P, 10, generator=g), torch.randn(P, 10, generator=g)
+        det_b = torch.randint(0, B, (P,), generator=g).sort().values
+        K = synthetic.get_camera_K(1288, B)
+        K[:, 0, 2] += torch.arange(B) * 4.0
+        K[:, 1, 1] *= 1.0 + 0.03 * torch.arange(B)
+        loc = 1288 * torch.rand(P, 2, generator=g)
+        dist = 2 + 6 * torch.rand(P, 1, generator=g)
+        ref = smpl_layer_forward(bm, pose, shape, loc, dist, K[det_b], expr, person_center_idx=15)
+        args = [d(pose), d(shape), d(expr), d(loc), d(dist), d(K), d(det_b, torch.int32)]
+        _lib.check(L.mhmr_lbs_forward(C.byref(cs), *[a.data_ptr() for a in args], P, wsF.data_ptr(), wsA.data_ptr(), wsX.data_ptr(),
+                                      v3d.data_ptr(), v2d.data_ptr(), j3d.data_ptr(), j2d.data_ptr(), transl.data_ptr(), stream()), "lbs")
+        worst3 = max(worst3, float((v3d.cpu() - ref["v3d"]).abs().max()), float((j3d.cpu() - ref["j3d"]).abs().max()))
+        worst2 = max(worst2, float((v2d.cpu() - ref["v2d"]).abs().max()), float((j2d.cpu() - ref["j2d"]).abs().max()))
+    assert worst3 < 2e-5, worst3           # metres
+    assert worst2 < 2e-2, worst2           # pixels at 1288^2 (focal ~1115 px: 2e-5 m at 2 m is 1e-2 px)
+
+
 def test_attention_is_bit_reproducible(L):
     """Regression: with the compiler-inserted waits only, hipcc hoisted the LDS-DMA vmcnt wait out of the KV loop and this
     configuration (several workgroups per CU) gave different results on every run."""

@@ -54,8 +54,8 @@ def test_training_mode_matches_reference_golden(name, precision, smplx_data, mea
 
 
 @pytest.mark.parametrize("precision", ["f16", "bf16"])
-def test_inference_mode_person_list_matches_reference_golden(precision, smplx_data, mean_params):
-    name = "vits_448_infer"
+@pytest.mark.parametrize("name", ["vits_448_infer", "vitl_448_infer"])      # depth-2 ViT-S; the FULL-depth ViT-L
+def test_inference_mode_person_list_matches_reference_golden(name, precision, smplx_data, mean_params):
     cfg = make_golden.CASES[name]
     gold = np.load(os.path.join(GOLD, name + ".npz"))
     sd = make_golden.case_state_dict(cfg)
@@ -71,6 +71,8 @@ def test_inference_mode_person_list_matches_reference_golden(precision, smplx_da
     assert humans[0]["scores"].dim() == 0 and humans[0]["transl_pelvis"].shape == (1, 3) and humans[0]["v3d"].shape == (10475, 3)
     for k in humans[0].keys():
         got = torch.stack([h[k] for h in humans]).cpu()
+        if k == "v3d":
+            got = got[:, :: cfg.get("vstride", 1)]
         if k == "rotvec":
             e = rel(roma_ref.rotvec_to_rotmat(got).numpy(), roma_ref.rotvec_to_rotmat(torch.from_numpy(gold["h_rotvec"])).numpy())
         else:
@@ -106,6 +108,46 @@ def test_forward_model_wrapper_and_autocast(smplx_data, mean_params):
     assert all(torch.equal(p["v3d"], q["v3d"]) for p, q in zip(a, b))
 
 
+def test_two_host_threads_two_streams_are_independent(smplx_data, mean_params):
+    """include/mhmr.h: every entry point is re-entrant across streams.  mhmr_vit_forward used to fork the V projection onto ONE
+    process-global side stream with ONE event pair, so two host threads driving two streams could interleave their record / wait calls
+    (ctypes releases the GIL) and a V GEMM could start before its own LayerNorm; now everything runs on the caller's stream.  Two
+    models with different weights, two threads, two streams, many interleaved forwards: every result bit-equal to the serial one."""
+    import threading
+    cfg = make_golden.CASES["vitl_224_train"]          # ViT-L: the token-row map, the class-row kernels and the folded LayerNorms run
+    x, K, idx = make_golden.case_inputs(cfg)
+    xc, Kc, ic = x.cuda(), K.cuda(), tuple(i.cuda() for i in idx)
+    sds = [make_golden.case_state_dict(cfg), synthetic.make_state_dict(cfg["backbone"], cfg["img_size"], seed=91, depth_override=cfg["depth_override"])]
+    models = [build(cfg, smplx_data, mean_params, "f16", sd) for sd in sds]
+    serial = [m(xc, idx=ic, K=Kc, is_training=True) for m in models]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in models]
+    results, errors = [[] for _ in models], []
+
+    def worker(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                for _ in range(6):
+                    results[i].append({k: v.clone() for k, v in models[i](xc, idx=ic, K=Kc, is_training=True).items()})
+            streams[i].synchronize()
+        except Exception as e:          # noqa: BLE001
+            errors.append(e)
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(models))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for i in range(len(models)):
+        for out in results[i]:
+            for k in ("scores", "v3d", "rotmat", "shape", "expression", "transl"):
+                assert torch.equal(out[k], serial[i][k]), (i, k)
+    assert not torch.equal(serial[0]["v3d"], serial[1]["v3d"])
+
+
 def test_load_state_dict_after_a_forward_repacks_everything(smplx_data, mean_params):
     """Regression (round-1 advisor finding): the cached workspace holds a descriptor with raw pointers into the packed weights; a
     forward, then load_state_dict(other weights), then a forward at the SAME batch size must run entirely on the new weights."""
@@ -122,7 +164,7 @@ def test_load_state_dict_after_a_forward_repacks_everything(smplx_data, mean_par
     for k in ("scores", "v3d", "rotmat", "shape", "transl"):
         assert torch.equal(out_b[k], fresh[k]), k
     assert not torch.equal(out_a["v3d"], out_b["v3d"])
-    # a different batch size afterwards replaces the workspace (one is cached, not one per size)
+    # a different batch size afterwards gets its own workspace (the two most recent sizes are cached)
     out_1 = m(xc[:1], idx=tuple(i[ic[0] == 0] for i in ic), K=Kc[:1], is_training=True)
     assert float((out_1["v3d"] - fresh["v3d"][ic[0] == 0]).abs().max()) < 1e-5
 
