@@ -28,11 +28,11 @@ class MhmrError(RuntimeError):
     pass
 
 
-#: per-translation-unit extra flags.  lbs.hip: hipcc's SLP vectoriser packs the per-vertex epilogue into v_pk_*_f32 with op_sel operand
-#: swizzles; that build returned, for about one (person, 16-vertex tile) pair in 10^4, a projection computed with a ZERO focal length
-#: (the y row of K: the other 15 pairs of the same wave were right; deterministic per build, tools/debug_lbs.py).  Scalar f32 code is
-#: also what the guide recommends beside MFMAs (MI355X_MICROARCH.md: packed f32 VALU is an anti-lever there).
-EXTRA_FLAGS = {"lbs.hip": ["-fno-slp-vectorize", "-DMHMR_NO_SLP"]}
+#: No SLP vectoriser in any translation unit (csrc/mhmr_common.h has the reasons and refuses a build without -DMHMR_NO_SLP): its
+#: op_sel-swizzled v_pk_*_f32 code returned wrong values in two kernels on gfx950, and the scalar build is 2 % faster.
+COMMON_FLAGS = ["-fno-slp-vectorize", "-DMHMR_NO_SLP"]
+#: per-translation-unit extra flags
+EXTRA_FLAGS = {}
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + COMMON_FLAGS
 
     def compile_one(name):
         obj = os.path.join(objdir, name.replace(".hip", ".o"))

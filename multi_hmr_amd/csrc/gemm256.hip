@@ -276,6 +276,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         // per quadrant, the wave's [32 Q-rows][64 P-cols] block is transposed through LDS so that global accesses are
         // whole contiguous row segments (a direct store from the MFMA layout camps on one memory channel).
         char* wl = smem + STAGE_OFF + w * 4096;
+        // (the folded-LayerNorm epilogues and the residual epilogue with its extra outputs need more address arithmetic than the others: with
+        // the lane index recomputed HERE, none of it is hoisted in front of the tile loop and kept alive -- i.e. spilled -- across the k loop)
+        constexpr bool RELANE = FOLD || EPI == EPI_RESID;
+        int lane_e = 0;
+        if constexpr (RELANE) {
+            lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(lane_e));
+        }
+        const int lane_outer = lane, l15_outer = l15, g4_outer = g4;
+        {
+        const int lane = RELANE ? lane_e : lane_outer;
+        const int l15 = RELANE ? (lane_e & 15) : l15_outer, g4 = RELANE ? (lane_e >> 4) : g4_outer;
         constexpr bool OUT16 = (EPI == EPI_OP16 || EPI == EPI_OP16_GELU || EPI == EPI_OP16_RELU || EPI == EPI_VT || EPI == EPI_OP16_QK);
         if constexpr (EPI == EPI_RESID) {
             // out32 += gamma * (acc + bias), in place.  8 passes (h, j, qs) of [16 rows][64 cols] fp32 per wave; a pass that
@@ -455,6 +467,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                     }
                 }
             }
+        }
         }
         }
         // drain: the epilogue's stores and the (long landed) next-tile DMA; re-establishes exact vmcnt accounting

@@ -26,15 +26,7 @@
 #include "mhmr_common.h"
 #include "mhmr_internal.h"
 
-// This file must be compiled with -fno-slp-vectorize (multi_hmr_amd/_lib.py EXTRA_FLAGS passes -DMHMR_NO_SLP beside it): hipcc's SLP
-// vectoriser packs the per-vertex projection epilogue into v_pk_*_f32 with op_sel operand swizzles, and that build returned a
-// projection computed with a zero focal length for about one (person, vertex tile) pair in 10^4 (tests/test_gpu_kernels.py::
-// test_lbs_max_abs_gate_160_persons_x_20_seeds is the gate).  The packed and the scalar instruction streams were compared line by line
-// (round 3): the operand selection of the packed form is arithmetically right, no wait state is missing by the ISA manual's table, so
-// the cause is unresolved; scalar f32 is also what the guide recommends beside MFMAs.  Any other build recipe fails HERE, not at run time.
-#ifndef MHMR_NO_SLP
-#error "csrc/lbs.hip: build with -fno-slp-vectorize -DMHMR_NO_SLP (see the comment above)"
-#endif
+// (built without the SLP vectoriser like every file here: mhmr_common.h has the history -- this kernel was the first casualty)
 
 namespace {
 

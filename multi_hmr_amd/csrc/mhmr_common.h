@@ -2,6 +2,23 @@
 // wave = 64 lanes; MFMA 32x32x16 (bf16|f16 operands, fp32 accumulate); LDS tiles are [rows][64] 16-bit
 // (128-byte rows) filled by global_load_lds_dwordx4 with an XOR swizzle applied on the SOURCE address.
 #pragma once
+// Every translation unit of this library must be compiled with -fno-slp-vectorize (multi_hmr_amd/_lib.py passes -DMHMR_NO_SLP beside it).
+// hipcc's SLP vectoriser turns groups of scalar fp32 operations into v_pk_{fma,mul,add}_f32 with op_sel operand swizzles; two kernels built
+// that way returned wrong values on gfx950 although the packed and the scalar instruction streams are arithmetically the same when read
+// line by line:
+//   lbs.hip      (round 2)  a projection computed with a zero focal length for about one (person, vertex tile) pair in 10^4, the same
+//                           pairs on every run of one build (tests/test_gpu_kernels.py::test_lbs_max_abs_gate_160_persons_x_20_seeds);
+//   vit_cls.hip  (round 3)  the class-row linear with the folded-LayerNorm epilogue: element 2 of lanes 48 ... 63 -- the low half of a
+//                           v_pk_fma_f32 whose addend is the result of the v_pk_fma_f32 right before it and whose multiplier is picked by
+//                           op_sel:[0,1,0] -- came out wrong in about 1 of 600 one-block forwards, and ONLY while a second stream kept the
+//                           CUs busy (serial runs are bit-reproducible): tests/test_gpu_model.py::
+//                           test_two_host_threads_two_streams_are_independent, tools/two_stream_check.py; 0 of 720 without SLP.
+// The no-SLP build has no op_sel-swizzled packed fp32 instruction left in any kernel (they were in all of them: 1472 in gemm256.hip,
+// 484 in attention.hip, 360 in hph.hip) and is also 2.1 % FASTER on the whole forward (138.9 vs 141.9 ms, same box, profiles/
+// r03_slp_ab.txt): scalar fp32 beside MFMAs is what MI355X_MICROARCH.md recommends.  Any other build recipe fails here, not at run time.
+#ifndef MHMR_NO_SLP
+#error "libmhmr: build every .hip file with -fno-slp-vectorize -DMHMR_NO_SLP (see the comment above)"
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/mhmr.h"

@@ -100,7 +100,7 @@ def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = N
 
     for i, b in enumerate(enc.blocks):
         blk = blocks[i]
-        f1, f2 = P["fold"] and i > 0, P["fold"]
+        f1, f2 = P["fold"] and i > 0, P["fold"]            # block 0's norm1 reads the patch embedding: no producer to fold into
         v_rows = slice(2 * Cd, 3 * Cd)
         blk.flags = (1 if f1 else 0) | (2 if f2 else 0)
         blk.proj_w2 = k(hi_lo(f32(b.attn.proj.weight), tdt)) if "proj" in lo_passes.get(i, ()) else None
