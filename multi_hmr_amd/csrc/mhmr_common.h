@@ -8,11 +8,15 @@
 // line by line:
 //   lbs.hip      (round 2)  a projection computed with a zero focal length for about one (person, vertex tile) pair in 10^4, the same
 //                           pairs on every run of one build (tests/test_gpu_kernels.py::test_lbs_max_abs_gate_160_persons_x_20_seeds);
-//   vit_cls.hip  (round 3)  the class-row linear with the folded-LayerNorm epilogue: element 2 of lanes 48 ... 63 -- the low half of a
-//                           v_pk_fma_f32 whose addend is the result of the v_pk_fma_f32 right before it and whose multiplier is picked by
-//                           op_sel:[0,1,0] -- came out wrong in about 1 of 600 one-block forwards, and ONLY while a second stream kept the
-//                           CUs busy (serial runs are bit-reproducible): tests/test_gpu_model.py::
-//                           test_two_host_threads_two_streams_are_independent, tools/two_stream_check.py; 0 of 720 without SLP.
+//   vit_cls.hip  (round 3)  the class-row linear with the folded-LayerNorm epilogue: elements 0 / 2 of lanes 48 ... 63 -- the LOW halves of
+//                           v_pk_fma_f32 ... op_sel:[0,1,0] (multiplier = the high dword of a register pair, for both halves) -- came
+//                           out wrong in 1 of 40 ... 600 forwards, and ONLY while a second stream kept foreign waves (MFMA GEMMs,
+//                           attention) on the same SIMDs: serial runs are bit-reproducible.  Re-assembling the same device code with
+//                           s_nop in front of every such instruction, or between the operand's load wait and its first use, lowers the
+//                           rate but does not remove it (profiles/r03_slp_waitstate_variants.txt), so it is not a missing wait state
+//                           of the dependent-instruction kind; without the SLP vectoriser: 0 of 720 (profiles/
+//                           r03_two_stream_slp_vs_noslp.txt).  Gate: tests/test_gpu_model.py::
+//                           test_two_host_threads_two_streams_are_independent; tool: tools/two_stream_check.py.
 // The no-SLP build has no op_sel-swizzled packed fp32 instruction left in any kernel (they were in all of them: 1472 in gemm256.hip,
 // 484 in attention.hip, 360 in hph.hip) and is also 2.1 % FASTER on the whole forward (138.9 vs 141.9 ms, same box, profiles/
 // r03_slp_ab.txt): scalar fp32 beside MFMAs is what MI355X_MICROARCH.md recommends.  Any other build recipe fails here, not at run time.

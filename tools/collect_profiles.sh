@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh rNN   ->  gpurun_out/rNN/{kernel_stats.txt, pmc.json, ...}; copy the summaries into profiles/.
 # Counters are collected in their own runs (one --pmc set per run, --kernel-trace only beside them).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT/pmc/lbs $OUT/trace
 cd /tmp && export TMPDIR=/tmp
@@ -14,9 +14,7 @@ if [ "$2" != "pmc" ]; then
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o headline --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --only-headline-kernels > $OUT/trace/headline.json 2> $OUT/trace/err_headline.txt
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/trace/bench.json 2> $OUT/trace/err.txt
 fi
-# counter passes: one kernel at a time -- the V projection stays on the main stream (its side-stream overlap with QK would only
-# smear the per-kernel durations the clock estimate divides by)
-export MHMR_QKV_OVERLAP=0
+# counter passes (every kernel of the forward runs on the caller's stream: one kernel at a time)
 SQSET="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc -o $c --output-format csv -- $BENCH > /dev/null 2>&1

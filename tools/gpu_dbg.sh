@@ -1,13 +1,10 @@
 #!/bin/bash
+# which instruction pattern of the SLP build of vit_cls.hip misbehaves: the same device assembly re-assembled unchanged (cls_slp),
+# with a wait state in front of every op_sel:[0,1,0] v_pk_fma_f32 (cls_varA), with wait states between the (mean, rstd) load and its use (cls_varB)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r03g; mkdir -p $OUT; cd $R
-for i in 1 2; do for lib in default build_ab/noslp build_ab/clsnoslp; do
-  echo "== $lib" >> $OUT/ab_slp.txt
-  python tools/run_with_lib.py $lib bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 >> $OUT/ab_slp.txt
-done; done
-python - <<'PY'
-import json
-for l in open("gpurun_out/r03g/ab_slp.txt"):
-    if l.startswith("=="): print(l.strip(), end="  ")
-    else:
-        d = json.loads(l); print(d["value"], d["ms_per_step"])
-PY
+{ for lib in build_ab/cls_slp build_ab/cls_varA build_ab/cls_varB build_ab/cls_slp; do
+    echo "=== lib '$lib'"
+    MHMR_LIBDIR=$lib REPS=400 python tools/two_stream_check.py 1 | cut -c1-200 | tail -3
+    MHMR_LIBDIR=$lib REPS=100 python tools/two_stream_check.py 4 | cut -c1-160 | tail -2
+  done; } > $OUT/dbg11.txt 2>&1
+grep -v amdgpu.ids $OUT/dbg11.txt | grep "===\|done"

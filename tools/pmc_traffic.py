@@ -13,7 +13,7 @@ usage: tools/pmc_traffic.py <dir with FETCH_SIZE_counter_collection.csv, WRITE_S
 import collections, csv, glob, hashlib, json, os, re, sys
 d = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PAT = re.compile(r"(gemm256_kernel<\d, \d>|gemm_kernel<\d, \d>|attn_kernel<[^>]*>|layernorm_kernel<[^>]*>|lbs_vertex_kernel|lbs_pose_kernel|lbs_extra_joints_kernel)")
+PAT = re.compile(r"(gemm256_kernel<[^>]*>|gemm_kernel<\d, \d>|cls_linear_kernel<[^>]*>|ln_stats_kernel|attn_kernel<[^>]*>|layernorm_kernel<[^>]*>|lbs_vertex_kernel|lbs_pose_kernel|lbs_extra_joints_kernel)")
 
 
 def find(dirname, counter):
