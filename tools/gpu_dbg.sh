@@ -1,10 +1,9 @@
 #!/bin/bash
-# which instruction pattern of the SLP build of vit_cls.hip misbehaves: the same device assembly re-assembled unchanged (cls_slp),
-# with a wait state in front of every op_sel:[0,1,0] v_pk_fma_f32 (cls_varA), with wait states between the (mean, rstd) load and its use (cls_varB)
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r03g; mkdir -p $OUT; cd $R
-{ for lib in build_ab/cls_slp build_ab/cls_varA build_ab/cls_varB build_ab/cls_slp; do
-    echo "=== lib '$lib'"
-    MHMR_LIBDIR=$lib REPS=400 python tools/two_stream_check.py 1 | cut -c1-200 | tail -3
-    MHMR_LIBDIR=$lib REPS=100 python tools/two_stream_check.py 4 | cut -c1-160 | tail -2
-  done; } > $OUT/dbg11.txt 2>&1
-grep -v amdgpu.ids $OUT/dbg11.txt | grep "===\|done"
+# attention forms on the no-SLP build: kernel alone and inside the forward
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r03i; mkdir -p $OUT; cd $R
+timeout 300 python tools/kbench.py --dtype f16 --only attn --variants 0,1,2,3,4,5 --iters 10 2>&1 | grep -v amdgpu.ids > $OUT/kb_attn.txt
+cat $OUT/kb_attn.txt
+for cfg in "X=1" "MHMR_ATTN_VARIANT=4" "MHMR_ATTN_VARIANT=5" "X=2" "MHMR_ATTN_VARIANT=4"; do
+  env $cfg timeout 400 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $OUT/b.json
+  echo "$cfg: $(python -c "import json; d=json.load(open('$OUT/b.json')); print(d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline_attention']['achieved'])")" | tee -a $OUT/ab_attn.txt
+done
