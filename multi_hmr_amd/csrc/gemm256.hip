@@ -53,6 +53,17 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+#ifdef MHMR_GEMM_STAMPS     // tools/gemm_timeline.py: per-workgroup, per-tile wall-clock stamps of wave 0 (debug build only, never in libmhmr.so)
+__device__ unsigned long long* g_gemm_stamps;
+__device__ int g_gemm_sametile;      // 1: every tile reads the operands of tile 0 (all L2 hits: the k loop without memory stalls); 2: ... of its first tile
+#define GEMM_STAMP(r, i)                                                                                                    \
+    do {                                                                                                                    \
+        if (g_gemm_stamps && threadIdx.x == 0 && (r) < 64) g_gemm_stamps[((size_t)blockIdx.x * 64 + (r)) * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define GEMM_STAMP(r, i)
+#endif
+
 // FOLD: a consumer of a folded LayerNorm (GemmArgs::rowstats; EPI_OP16_QK / EPI_VT / EPI_OP16_GELU only) -- a kernel of its own, so that
 // the plain epilogues keep their 32-row staging passes and carry no run-time switches
 template <int DT, int EPI, bool FOLD = false>
@@ -99,6 +110,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     // (the image of a row tile by a host-made reciprocal, GemmArgs::img_magic: a run-time integer division here costs a dozen live
     // vector registers in a kernel that has none to spare)
     auto tile_src = [&](int tix, const T*& pb, const T*& qb, int& p0, int& q0, int& ar, int& bimg) {
+#ifdef MHMR_GEMM_STAMPS
+        if (g_gemm_sametile == 1) tix = 0;
+        if (g_gemm_sametile == 2) tix = (int)blockIdx.x;
+#endif
         const int tn = tix % nbn, tm = tix / nbn;
         p0 = ROWMAJOR ? tn * 256 : tm * 256;
         q0 = ROWMAJOR ? tm * 256 : tn * 256;
@@ -181,6 +196,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     // indices (b < ntiles % G): when another persistent launch is draining beside this one, the workgroups dispatched first are
     // then the ones with the extra tile
     const int full = ntiles / G, nmine = full + (b < ntiles - full * G ? 1 : 0);
+    // (walking the rounds of qk / v / fc1 downwards, so that they start with the rows the residual GEMM before them wrote last -- still in
+    // the Infinity Cache -- measured +0.1 %: not kept)
     auto tile_of = [&](int r) {
         if (r >= full) return full * G + b;
         if (colgroup) {
@@ -207,6 +224,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     MHMR_SYNC();
 
     for (int r = 0; r < nmine; ++r) {
+        GEMM_STAMP(r, 0);
         // Q0 of this tile's first K tile (landed and published by the previous pair's phase-8 wait + barrier, or by the prologue)
         rdQ(QA, 0, SLOT_Q0);
         if (wp == 1) { MHMR_SYNC(); }       // stagger: during the K loop group 1 runs one barrier behind group 0
@@ -271,7 +289,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
             MHMR_SYNC(); mma(acc[1][1], QB); MHMR_SYNC();
         }
 
+        GEMM_STAMP(r, 1);
         if (wp == 0) { MHMR_SYNC(); }       // re-align: both groups run the memory-bound epilogue together
+        GEMM_STAMP(r, 2);
         // ---- epilogue (wave-private staging; the next tile's DMA is in flight underneath) ----
         // per quadrant, the wave's [32 Q-rows][64 P-cols] block is transposed through LDS so that global accesses are
         // whole contiguous row segments (a direct store from the MFMA layout camps on one memory channel).
@@ -298,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
             // the HBM floor.  Also measured and rejected (round 2): the residual tile as the accumulators' INITIAL value (LayerScale
             // folded into W, epilogue write-only) -- the 32 fragment-shaped loads per lane (16 rows x 64 B each) cost more than the
             // read-modify-write they replace: proj 0.351 -> 0.372 ms, fc2 0.977 -> 1.006 ms (f16).
-            constexpr int RD = 1;
+            constexpr int RD = 1;          // (RD = 2, 247 VGPRs, re-measured in round 3 with the staggered quarters in place: no change; RD = 3 spills)
             const int c = lane & 15;
             // 32-bit byte offsets from the uniform base (eligibility guarantees M * ldo * 4 < 2^32): one VGPR per address
             const uint32_t off0 = ((uint32_t)(ar + 32 * wq + (lane >> 4)) * (uint32_t)g.ldo + (uint32_t)(p0 + 64 * wp + 4 * c)) * 4u;
@@ -471,12 +491,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         }
         }
         // drain: the epilogue's stores and the (long landed) next-tile DMA; re-establishes exact vmcnt accounting
+        GEMM_STAMP(r, 3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GEMM_STAMP(r, 4);
         p_src = p_nxt; q_src = q_nxt; p0 = p0n; q0 = q0n; ar = arn; bimg = bimgn;
     }
 #undef MHMR_SYNC
 #undef MHMR_WAIT_DMA
 }
+
+#ifdef MHMR_GEMM_STAMPS
+}  // namespace
+extern "C" int mhmr_debug_gemm_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), &p, sizeof(p)); }
+extern "C" int mhmr_debug_gemm_sametile(int v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_sametile), &v, sizeof(v)); }
+namespace {
+#endif
 
 template <int DT>
 int launch256_dt(const GemmArgs& g, hipStream_t s) {
