@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define MHMR_VERSION 101   /* 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
+#define MHMR_VERSION 102   /* 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
 
 #define MHMR_OK 0
 #define MHMR_ERR_BAD_ARG (-1)
@@ -253,7 +253,10 @@ int mhmr_layernorm_f32(const float* in, const float* w, const float* b, float* o
  * roma.rotvec_to_rotmat (:107), inverse_perspective_projection (:117-123), perspective_projection (:143-144).
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct {
-    int V, Vp;            /* 10475, V rounded up to a multiple of 48 (the vertex kernel's tile)               */
+    int V, Vp, Vl;        /* 10475; columns of the vertex kernel's operands: V rounded up to a multiple of 48 (= Vl, the kernel's tile) + the
+                             tiles of the 72 extra joints (21 picked vertices + 51 barycentric landmarks) as VIRTUAL vertices: extra
+                             joint e = 16 t + i owns column Vl + 48 t + 16 k + i, k = 0..2 = copies of its three corner vertices' columns
+                             (a picked vertex: three copies of itself), Vp = Vl + 48 * 5                                       */
     int Kb;               /* 486 + nb + 10 rounded up to a multiple of 32 (width of the feature rows F); the vertex kernel is built for
                              Kb == 512, i.e. num_betas <= 16 (MHMR_ERR_BAD_SHAPE otherwise)                     */
     int nb, Kinf;         /* num_betas, max skinning influences per vertex                                   */
@@ -269,9 +272,8 @@ typedef struct {
     const float* skin_w;  /* [V][Kinf]                                                                       */
     const void* skin16;   /* f16 [Vp/48][8][2][48][8]: the DENSE skinning weights w[v][j] (joints 55..63 zero), hi + lo,
                              j = 8 * block + lane-local index: the B operand of the skinning GEMM            */
-    const int* extra_vid; /* [21]              vertex ids of joints 55..75                                   */
-    const int* lmk_vidx;  /* [51*3]            faces[lmk_faces_idx]                                          */
-    const float* lmk_bary;/* [51*3]                                                                          */
+    const float* xbary;   /* [72*3]            corner weights of the extra joints: (1, 0, 0) for joints 55..75 (vertices picked by id),
+                             lmk_bary_coords for 76..126 (faces[lmk_faces_idx] are the corners)                 */
 } mhmr_lbs_consts;
 
 /* rotvec [P,53,3], betas [P,nb], expr [P,10], loc [P,2], dist [P], K [B,3,3], det_b [P] (image of each person).

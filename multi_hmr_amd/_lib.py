@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(CSRC, "libmhmr.so")
 SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "vit_misc.hip", "vit_cls.hip", "hph.hip", "lbs.hip", "preprocess.hip", "evalm.hip", "anny.hip", "capi.hip"]
 HEADERS = ["mhmr_common.h", "mhmr_internal.h", os.path.join("..", "..", "include", "mhmr.h")]
 
-VERSION = 101                       # include/mhmr.h MHMR_VERSION (struct layouts and entry-point semantics)
+VERSION = 102                       # include/mhmr.h MHMR_VERSION (struct layouts and entry-point semantics)
 DT_BF16, DT_F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 EPI_OP16, EPI_OP16_GELU, EPI_OP16_RELU, EPI_RESID, EPI_PATCH, EPI_F32, EPI_VT, EPI_OP16_QK = range(8)
@@ -96,8 +96,8 @@ class HphDesc(C.Structure):
 
 
 class LbsConsts(C.Structure):
-    _fields_ = ([(n, _i) for n in ("V", "Vp", "Kb", "nb", "Kinf", "center_joint")] +
-                [(n, _vp) for n in ("basis16", "vtemp", "J0", "JS", "parents", "skin_idx", "skin_w", "skin16", "extra_vid", "lmk_vidx", "lmk_bary")])
+    _fields_ = ([(n, _i) for n in ("V", "Vp", "Vl", "Kb", "nb", "Kinf", "center_joint")] +
+                [(n, _vp) for n in ("basis16", "vtemp", "J0", "JS", "parents", "skin_idx", "skin_w", "skin16", "xbary")])
 
 
 _SIGS = {

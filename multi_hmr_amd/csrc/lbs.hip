@@ -1,5 +1,5 @@
 // SMPL-X linear blend skinning + camera placement (reference blocks/smpl_layer.py:47-155 -> smplx.SMPLX.forward
-// -> lbs), three launches:
+// -> lbs), two launches:
 //
 //  1. lbs_pose_kernel   (one wave per person)  Rodrigues x55, pose feature, joint regression from the
 //     pre-contracted regressor (J = J0 + JS.[betas, expr]), kinematic chain, root rotation / recentring /
@@ -22,7 +22,10 @@
 //     History at 160 persons: fp32 MFMA 108 us (matrix-bound); split-f16 blend + sparse gathered skinning 74 us; 16-vertex tiles with
 //     the skinning as a GEMM 54.7 us, with explicit operand prefetch 48.6 us (both bound by the vector-memory path feeding the A
 //     operands, see the kernel); this form 31.4 us (matrix pipe ~55 % busy on the 219 CUs that hold a tile).
-//  3. lbs_extra_joints_kernel  the 21 vertex-picked joints and 51 barycentric face landmarks.
+//     The 72 extra joints (21 vertices picked by id, 51 barycentric face landmarks: joints 55..126) are five more tiles of VIRTUAL
+//     vertices behind the real ones (packing.pack_smplx: copies of their corner vertices' operand columns, arranged so that ONE lane ends
+//     up with the three posed corners of an extra joint): they cost 5 of 224 workgroups on otherwise idle CUs instead of a third launch
+//     (round 2: lbs_extra_joints_kernel, 3.4 us + a launch gap behind the vertex kernel).
 #include "mhmr_common.h"
 #include "mhmr_internal.h"
 
@@ -298,6 +301,7 @@ struct __attribute__((packed, aligned(4))) Vec2 { float x, y; };
 constexpr int LBS_TV = 48, LBS_NST = LBS_TV / 16;      // vertices per tile, 16-vertex MFMA column blocks per tile
 constexpr int LBS_NC = 10, LBS_NL = 2;                 // compute waves (one person group each), loader waves
 constexpr int LBS_KB = 512;                            // padded blend depth (486 pose + betas + 10 expression <= 512)
+constexpr int LBS_NX = 72;                             // extra joints 55..126 (virtual vertices in the tiles from c.Vl on)
 constexpr int LBS_NS = LBS_KB / 32;                    // k steps of 32
 constexpr int LBS_NE = 8, LBS_RING = 3;                // k eighths (2 steps each), LDS ring slots
 constexpr int LBS_ROW = LBS_TV * 8 * 2;                // bytes of one (k block, part, axis) row of the tile: 48 vertices x 8 k x f16
@@ -372,7 +376,7 @@ __device__ __forceinline__ void lbs_loader(const mhmr_lbs_consts& c, const float
 // compute wave: person group g (16 persons) against the tile's 48 vertices
 __device__ __forceinline__ void lbs_compute(const mhmr_lbs_consts& c, const _Float16* __restrict__ F16, const _Float16* __restrict__ A16,
                                             int P, int ngroups, int g, int w, float* __restrict__ v3d, float* __restrict__ v2d,
-                                            const char* smem) {
+                                            float* __restrict__ j3d, float* __restrict__ j2d, const char* smem) {
     typedef Op<MHMR_DT_F16>::V8 H8;
     const int lane = threadIdx.x & 63;
     const int g4 = lane >> 4, l15 = lane & 15;
@@ -493,22 +497,53 @@ __device__ __forceinline__ void lbs_compute(const mhmr_lbs_consts& c, const _Flo
     LBS_STAMP(10);
     // ---- camera translation (fp32, exactly where the reference adds it: smpl_layer.py:139-140), projection, stores ----
     const char* xrec = smem + LBS_RING * LBS_EBYTES + w * (16 * LBS_XREC);
+    if (v0 < c.Vl) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int p = 16 * g + 4 * g4 + r;
-        if (p >= P) continue;
-        const f32x4* Xr = (const f32x4*)(xrec + (4 * g4 + r) * LBS_XREC + 48);      // [o (3), K (9)]
-        const f32x4 x0 = Xr[0], x1 = Xr[1], x2 = Xr[2];
+        for (int r = 0; r < 4; ++r) {
+            const int p = 16 * g + 4 * g4 + r;
+            if (p >= P) continue;
+            const f32x4* Xr = (const f32x4*)(xrec + (4 * g4 + r) * LBS_XREC + 48);      // [o (3), K (9)]
+            const f32x4 x0 = Xr[0], x1 = Xr[1], x2 = Xr[2];
 #pragma unroll
-        for (int st = 0; st < LBS_NST; ++st) {
-            const int v = v0 + 16 * st + l15;
-            if (v >= c.V) continue;
-            const float ox = o3[st][0][r] + x0[0], oy = o3[st][1][r] + x0[1], oz = o3[st][2][r] + x0[2];
-            *(Vec3*)(v3d + ((size_t)p * c.V + v) * 3) = Vec3{ox, oy, oz};          // one 12-byte store (dword-aligned)
-            // perspective_projection (utils/camera.py:14-27) with one reciprocal instead of three divisions (<= 1 ulp apart)
-            const float iz = __builtin_amdgcn_rcpf(oz);
-            const float yx = ox * iz, yy = oy * iz, yz = oz * iz;
-            *(Vec2*)(v2d + ((size_t)p * c.V + v) * 2) = Vec2{x0[3] * yx + x1[0] * yy + x1[1] * yz, x1[2] * yx + x1[3] * yy + x2[0] * yz};
+            for (int st = 0; st < LBS_NST; ++st) {
+                const int v = v0 + 16 * st + l15;
+                if (v >= c.V) continue;
+                const float ox = o3[st][0][r] + x0[0], oy = o3[st][1][r] + x0[1], oz = o3[st][2][r] + x0[2];
+                *(Vec3*)(v3d + ((size_t)p * c.V + v) * 3) = Vec3{ox, oy, oz};          // one 12-byte store (dword-aligned)
+                // perspective_projection (utils/camera.py:14-27) with one reciprocal instead of three divisions (<= 1 ulp apart)
+                const float iz = __builtin_amdgcn_rcpf(oz);
+                const float yx = ox * iz, yy = oy * iz, yz = oz * iz;
+                *(Vec2*)(v2d + ((size_t)p * c.V + v) * 2) = Vec2{x0[3] * yx + x1[0] * yy + x1[1] * yz, x1[2] * yx + x1[3] * yy + x2[0] * yz};
+            }
+        }
+    } else {
+        // A tile of EXTRA JOINTS (joints 55..126: 21 vertices picked by id, 51 barycentric face landmarks -- smplx vertices2landmarks):
+        // extra joint e = 16 t + l15 owns column l15 of the tile's three vertex blocks (copies of its three corner vertices' operand
+        // columns, packing.pack_smplx), so this lane holds all three posed corners.  Affine in the corners: sum_k b_k (x_k + o) and, where
+        // the weights do not sum to exactly one, the (1 - sum) (o - R0 pelvis) part of the placement; a picked vertex is (1, 0, 0): the
+        // sums below then reproduce the vertex path bit for bit (0 * x = 0, x - 0 = x).
+        const int e = ((v0 - c.Vl) / LBS_TV) * 16 + l15;
+        if (e < LBS_NX) {
+            const float b0 = c.xbary[e * 3], b1 = c.xbary[e * 3 + 1], b2 = c.xbary[e * 3 + 2];
+            const float rest = 1.f - ((b0 + b1) + b2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = 16 * g + 4 * g4 + r;
+                if (p >= P) continue;
+                const float* X = (const float*)(xrec + (4 * g4 + r) * LBS_XREC);          // [R0 (9), pelvis (3), o (3), K (9)]
+                const f32x4* Xr = (const f32x4*)(X + 12);
+                const f32x4 x0 = Xr[0], x1 = Xr[1], x2 = Xr[2];
+                float rp[3];
+                mat3_vec(X, X + 9, rp);                                                     // R0 . pelvis
+                float q[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    q[a] = (((b0 * o3[0][a][r] + b1 * o3[1][a][r]) + b2 * o3[2][a][r]) + x0[a]) - rest * rp[a];
+                *(Vec3*)(j3d + ((size_t)p * 127 + 55 + e) * 3) = Vec3{q[0], q[1], q[2]};
+                const float iz = __builtin_amdgcn_rcpf(q[2]);
+                const float yx = q[0] * iz, yy = q[1] * iz, yz = q[2] * iz;
+                *(Vec2*)(j2d + ((size_t)p * 127 + 55 + e) * 2) = Vec2{x0[3] * yx + x1[0] * yy + x1[1] * yz, x1[2] * yx + x1[3] * yy + x2[0] * yz};
+            }
         }
     }
     LBS_STAMP(11);
@@ -517,7 +552,8 @@ __device__ __forceinline__ void lbs_compute(const mhmr_lbs_consts& c, const _Flo
 __global__ __launch_bounds__(64 * (LBS_NC + LBS_NL), 3) void lbs_vertex_kernel(const mhmr_lbs_consts c, const _Float16* __restrict__ F16,
                                                                                const _Float16* __restrict__ A16, const float* __restrict__ xf,
                                                                                int P, int Pp, int g0, float* __restrict__ v3d,
-                                                                               float* __restrict__ v2d) {
+                                                                               float* __restrict__ v2d, float* __restrict__ j3d,
+                                                                               float* __restrict__ j2d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ngroups = Pp / 16;
@@ -526,49 +562,10 @@ __global__ __launch_bounds__(64 * (LBS_NC + LBS_NL), 3) void lbs_vertex_kernel(c
     if (w >= LBS_NC) {
         lbs_loader(c, xf, P, ngroups, g0, smem, w - LBS_NC);
     } else if (g0 + w < ngroups) {
-        lbs_compute(c, F16, A16, P, ngroups, g0 + w, w, v3d, v2d, smem);
+        lbs_compute(c, F16, A16, P, ngroups, g0 + w, w, v3d, v2d, j3d, j2d, smem);
     } else {
 #pragma unroll
         for (int e = 0; e < LBS_NE; ++e) lbs_barrier();
-    }
-}
-
-// joints 55..75 = vertices picked by id; 76..126 = barycentric face landmarks (smplx vertices2landmarks).
-// Both are affine in the vertices, so they are taken from the placed v3d; a landmark whose barycentric
-// weights do not sum to exactly one gets the (1 - sum) * (o - R0 pelvis) correction of the affine part.
-__global__ __launch_bounds__(128) void lbs_extra_joints_kernel(const mhmr_lbs_consts c, const float* __restrict__ v3d,
-                                                               const float* __restrict__ v2d, const float* __restrict__ xf,
-                                                               float* __restrict__ j3d, float* __restrict__ j2d) {
-    const int p = blockIdx.x, i = threadIdx.x;
-    const float* X = xf + (size_t)p * 24;
-    if (i < 21) {
-        const int vid = c.extra_vid[i];
-        const float* s3 = v3d + ((size_t)p * c.V + vid) * 3;
-        const float* s2 = v2d + ((size_t)p * c.V + vid) * 2;
-        float* d3 = j3d + ((size_t)p * 127 + 55 + i) * 3;
-        float* d2 = j2d + ((size_t)p * 127 + 55 + i) * 2;
-        d3[0] = s3[0]; d3[1] = s3[1]; d3[2] = s3[2];
-        d2[0] = s2[0]; d2[1] = s2[1];
-    } else if (i < 72) {
-        const int l = i - 21;
-        float acc[3] = {0.f, 0.f, 0.f}, bs = 0.f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float bk = c.lmk_bary[l * 3 + k];
-            const float* s3 = v3d + ((size_t)p * c.V + c.lmk_vidx[l * 3 + k]) * 3;
-            acc[0] += bk * s3[0]; acc[1] += bk * s3[1]; acc[2] += bk * s3[2];
-            bs += bk;
-        }
-        float rp[3];
-        mat3_vec(X, X + 9, rp);  // R0 . pelvis
-#pragma unroll
-        for (int a = 0; a < 3; ++a) acc[a] += (1.f - bs) * (X[12 + a] - rp[a]);
-        float* d3 = j3d + ((size_t)p * 127 + 76 + l) * 3;
-        d3[0] = acc[0]; d3[1] = acc[1]; d3[2] = acc[2];
-        float pr[2];
-        project(X + 15, acc, pr);
-        float* d2 = j2d + ((size_t)p * 127 + 76 + l) * 2;
-        d2[0] = pr[0]; d2[1] = pr[1];
     }
 }
 
@@ -584,7 +581,9 @@ extern "C" int mhmr_lbs_forward(const mhmr_lbs_consts* c, const float* rotvec, c
                                 void* stream) {
     if (!c || P < 0) return MHMR_ERR_BAD_ARG;
     if (P == 0) return 0;
-    if (c->Vp % LBS_TV || c->Vp < c->V || c->Kb != LBS_KB || c->Kb < 486 + c->nb + 10 || !c->skin16) return MHMR_ERR_BAD_SHAPE;
+    if (c->Vp % LBS_TV || c->Vl % LBS_TV || c->Vl < c->V || c->Vp != c->Vl + LBS_TV * ((LBS_NX + 15) / 16) || c->Kb != LBS_KB ||
+        c->Kb < 486 + c->nb + 10 || !c->skin16 || !c->xbary)
+        return MHMR_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int Pp = (P + 15) / 16 * 16;
     {   // 126 KB of dynamic LDS: above the default per-kernel limit.  The attribute is per DEVICE: set it on every call (cheap) rather
@@ -600,10 +599,8 @@ extern "C" int mhmr_lbs_forward(const mhmr_lbs_consts* c, const float* rotvec, c
     prof_begin(PROF_LBS, s);
     for (int g0 = 0; g0 < ngroups; g0 += LBS_NC)
         hipLaunchKernelGGL(lbs_vertex_kernel, dim3(c->Vp / LBS_TV), dim3(64 * (LBS_NC + LBS_NL)), LBS_LDS, s, *c, (const _Float16*)ws_F,
-                           (const _Float16*)ws_A, ws_xf, P, Pp, g0, v3d, v2d);
+                           (const _Float16*)ws_A, ws_xf, P, Pp, g0, v3d, v2d, j3d, j2d);
     prof_end(PROF_LBS, s, (double)P);
-    MHMR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(lbs_extra_joints_kernel, dim3(P), dim3(128), 0, s, *c, v3d, v2d, ws_xf, j3d, j2d);
     MHMR_CHECK_LAUNCH();
     return 0;
 }

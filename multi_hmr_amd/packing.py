@@ -55,6 +55,8 @@ def interpolate_pos_embed(pos_embed: np.ndarray, G: int, offset: float = 0.1) ->
 # ---------------------------------------------------------------------------------------------- SMPL-X
 #: vertices per workgroup tile of the vertex kernel (csrc/lbs.hip LBS_TV)
 LBS_TILE = 48
+#: joints 55..126 of the 127 the SMPL-X layer returns: 21 vertices picked by id + 51 barycentric face landmarks
+N_EXTRA_JOINTS = 72
 
 
 def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) -> dict:  # person_center_idx < 0: no recentring
@@ -65,7 +67,11 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
       column blocks): one 16-byte line per lane is the 16x16x32 MFMA operand for 8 consecutive k; the template stays fp32 ([3][Vp]);
     * the dense joint regressor is pre-contracted with the template and the blend shapes (J = J0 + JS.coef);
     * skinning weights: the dense [64, Vp] matrix as an f16 pair hi + lo in MFMA operand order (``skin16``; the kernel blends the
-      joint transforms as a GEMM), plus the K-sparse (index, weight) list, K = max non-zeros per vertex (tools / tests).
+      joint transforms as a GEMM), plus the K-sparse (index, weight) list, K = max non-zeros per vertex (tools / tests);
+    * the 72 extra joints (21 vertices picked by id + 51 barycentric face landmarks, smplx ``vertices2landmarks``) are VIRTUAL vertices:
+      five more 48-vertex tiles after the real ones (from vertex ``Vl`` on) in which extra joint e = 16 t + i owns column i of the three
+      16-vertex blocks of tile t -- copies of the basis / template / skinning columns of its three corner vertices -- so that one lane of
+      the vertex kernel ends up with all three posed corners and combines them with ``xbary[e]`` ((1, 0, 0) for a picked vertex).
     """
     from .constants import SMPLX_EXTRA_JOINT_VERTS
     f64 = lambda a: np.asarray(a, dtype=np.float64)
@@ -77,10 +83,26 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
     assert pd.shape[-1] == 486
     ncoef = num_betas + 10
     Kb = roundup(486 + ncoef, 32)
-    Vp = roundup(V, LBS_TILE)
+    # extra joints 55..126 as virtual vertices: corner k of extra joint e sits at Vl + 48 (e // 16) + 16 k + e % 16
+    faces = np.asarray(data["f"], dtype=np.int64)
+    lmk_vidx = faces[np.asarray(data["lmk_faces_idx"], dtype=np.int64)].astype(np.int32)       # [51,3]
+    picked = np.asarray(SMPLX_EXTRA_JOINT_VERTS, dtype=np.int32)
+    xcorner = np.concatenate([np.repeat(picked[:, None], 3, axis=1), lmk_vidx], axis=0)         # [72,3] source vertex of every corner
+    xbary = np.concatenate([np.tile(np.array([[1.0, 0.0, 0.0]], dtype=np.float32), (len(picked), 1)),
+                            np.asarray(data["lmk_bary_coords"], dtype=np.float32)], axis=0)     # [72,3]
+    NX = xcorner.shape[0]
+    assert NX == N_EXTRA_JOINTS
+    Vl = roundup(V, LBS_TILE)
+    Vp = Vl + LBS_TILE * ((NX + 15) // 16)
+    src = np.full(Vp, -1, dtype=np.int64)                                                        # source vertex of every column (-1: zero padding)
+    src[:V] = np.arange(V)
+    e = np.arange(NX)
+    for k in range(3):
+        src[Vl + 48 * (e // 16) + 16 * k + e % 16] = xcorner[:, k]
+    live = src >= 0
     D = np.zeros((Kb, 3, Vp), dtype=np.float64)
-    D[:486, :, :V] = pd.transpose(2, 1, 0)
-    D[486:486 + ncoef, :, :V] = shp.transpose(2, 1, 0)
+    D[:486, :, live] = pd.transpose(2, 1, 0)[:, :, src[live]]
+    D[486:486 + ncoef, :, live] = shp.transpose(2, 1, 0)[:, :, src[live]]
     Ds = (D * 1024.0).astype(np.float32)
     hi = Ds.astype(np.float16)
     lo = (Ds - hi.astype(np.float32)).astype(np.float16)
@@ -96,7 +118,7 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
     lay = lambda a: a.reshape(Kb // 8, 8, 3, Vp // T, T).transpose(3, 0, 2, 4, 1)           # [Vp/48, Kb/8, 3, 48, 8]
     basis16 = np.ascontiguousarray(np.stack([lay(hi), lay(lo)], axis=2))                    # [Vp/48, Kb/8, 2, 3, 48, 8]
     vtemp = np.zeros((3, Vp), dtype=np.float32)
-    vtemp[:, :V] = v_t.T
+    vtemp[:, live] = v_t.T[:, src[live]]
 
     Jr = f64(data["J_regressor"])
     J0 = Jr @ v_t                                                                             # [55,3]
@@ -111,7 +133,7 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
 
     # dense weights as the B operand of the skinning GEMM: [8 joint blocks][hi | lo][Vp][8], joints 55..63 and vertices >= V zero
     Wd = np.zeros((64, Vp), dtype=np.float32)
-    Wd[: W.shape[1], :V] = W.T.astype(np.float32)
+    Wd[: W.shape[1], live] = W.T.astype(np.float32)[:, src[live]]
     whi = Wd.astype(np.float16)
     wlo = (Wd - whi.astype(np.float32)).astype(np.float16)
     if not bool((np.abs(whi.astype(np.float64) + wlo.astype(np.float64) - Wd) <= 2.0 ** -22 * np.abs(Wd) + 2.0 ** -25).all()):
@@ -121,15 +143,13 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
 
     parents = np.asarray(data["kintree_table"])[0].astype(np.int64).copy()
     parents[0] = -1
-    faces = np.asarray(data["f"], dtype=np.int64)
-    lmk_vidx = faces[np.asarray(data["lmk_faces_idx"], dtype=np.int64)].astype(np.int32)       # [51,3]
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dt)
     return {
-        "V": V, "Vp": Vp, "Kb": Kb, "nb": num_betas, "Kinf": Kinf, "center_joint": person_center_idx,
+        "V": V, "Vp": Vp, "Vl": Vl, "Kb": Kb, "nb": num_betas, "Kinf": Kinf, "center_joint": person_center_idx,
         "basis16": t(basis16, torch.float16), "vtemp": t(vtemp, torch.float32), "J0": t(J0, torch.float32), "JS": t(JS.reshape(55 * 3, ncoef), torch.float32),
         "parents": t(parents.astype(np.int32), torch.int32), "skin_idx": t(skin_idx, torch.int32), "skin_w": t(skin_w, torch.float32),
         "skin16": t(skin16, torch.float16),
-        "extra_vid": t(np.asarray(SMPLX_EXTRA_JOINT_VERTS, dtype=np.int32), torch.int32), "lmk_vidx": t(lmk_vidx, torch.int32),
+        "xbary": t(xbary, torch.float32), "extra_vid": t(picked, torch.int32), "lmk_vidx": t(lmk_vidx, torch.int32),
         "lmk_bary": t(np.asarray(data["lmk_bary_coords"], dtype=np.float32), torch.float32),
         "faces": faces,
     }
@@ -137,8 +157,8 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
 
 def lbs_consts_struct(p: dict) -> "_lib.LbsConsts":
     c = _lib.LbsConsts()
-    for k in ("V", "Vp", "Kb", "nb", "Kinf", "center_joint"):
+    for k in ("V", "Vp", "Vl", "Kb", "nb", "Kinf", "center_joint"):
         setattr(c, k, int(p[k]))
-    for k in ("basis16", "vtemp", "J0", "JS", "parents", "skin_idx", "skin_w", "skin16", "extra_vid", "lmk_vidx", "lmk_bary"):
+    for k in ("basis16", "vtemp", "J0", "JS", "parents", "skin_idx", "skin_w", "skin16", "xbary"):
         setattr(c, k, p[k].data_ptr())
     return c

@@ -617,6 +617,13 @@ def test_lbs_against_oracle(L, smplx_data, P, center):
         err = float((got.cpu() - ref[name]).abs().max())
         assert err < 5e-3, (name, err)                        # pixels
     assert float((j3d[:, [0]].cpu() - ref["transl_pelvis"]).abs().max()) < 2e-5
+    # joints 55..75 are vertices picked by id: the extra-joint tiles of the vertex kernel (virtual vertices with corner weights (1, 0, 0))
+    # must reproduce those vertices bit for bit, in 3D and in the image
+    vid = pk["extra_vid"].long()
+    assert torch.equal(j3d[:, 55:76], v3d[:, vid]) and torch.equal(j2d[:, 55:76], v2d[:, vid])
+    # joints 76..126: barycentric face landmarks against the same combination of the kernel's own vertices (fp32 rounding order only)
+    lm = (v3d[:, pk["lmk_vidx"].long()] * pk["lmk_bary"][None, :, :, None]).sum(2)
+    assert float((j3d[:, 76:] - lm).abs().max()) < 2e-6
 
 
 def test_lbs_max_abs_gate_160_persons_x_20_seeds(L, smplx_data):
