@@ -269,10 +269,13 @@ int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s) {
         // The residual epilogue moves 512 KiB per tile and all CUs reach it together: the round's 134 MB burst runs at the HBM
         // floor while the MFMAs idle.  Starting the CU quarters 0/1/2/3 quarter-periods apart interleaves the bursts with the
         // other quarters' K loops (proj 0.375 -> 0.350 ms, fc2 0.967 -> 0.953 ms; bias/GELU/V^T epilogues measured no gain).
-        // Period estimate: 1.4 us per K tile + 18 us epilogue.  MHMR_STAGGER_PCT scales it (0 = off).
+        // Period estimate: 1.4 us per K tile + 18 us epilogue.  MHMR_STAGGER_PCT scales it (0 = off).  With the token-row map (exact
+        // tile rounds, 8 tiles per CU) the late quarters' tail costs what the interleaving saves: off there (round 3, one box:
+        // 136.7 ms per step without, 137.3 with; profiles/r03_gemm_negative_results.txt).
         static const char* st = getenv("MHMR_STAGGER_PCT");
-        if (g.epi == EPI_RESID && (g.M / 256) * (g.N / 256) >= 1024)      // only when every CU walks several tiles
-            g2.stagger_ticks = (int)((g.K / 64 * 1.4 + 18.0) * 25.0 * (st ? atoi(st) : 100) / 100.0);
+        const int pct = st ? atoi(st) : (g.img_rows > 0 ? 0 : 100);
+        if (g.epi == EPI_RESID && (g.M / 256) * (g.N / 256) >= 1024 && pct > 0)      // only when every CU walks several tiles
+            g2.stagger_ticks = (int)((g.K / 64 * 1.4 + 18.0) * 25.0 * pct / 100.0);
         static const char* cg = getenv("MHMR_COLGROUP");
         g2.colgroup = cg ? atoi(cg) : 1;
         // image of a row tile = umulhi(tm, magic), exact while tm * tiles_per_image < 2^32; one tile per image: magic 0 = identity

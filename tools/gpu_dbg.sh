@@ -1,6 +1,5 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r03l; mkdir -p $OUT; cd $R
-timeout 600 python -m pytest tests/test_gpu_kernels.py -q -k "lbs" -p no:cacheprovider 2>&1 | tail -5 | tee $OUT/pytest_lbs.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a $OUT/pytest_lbs.txt
-for P in 160 20 1 300; do timeout 120 python tools/lbs_bench.py $P 2>&1 | grep -v amdgpu.ids | tail -2 | tee -a $OUT/lbs_bench.txt; done
-timeout 600 python -m pytest tests/test_gpu_model.py -q -k "golden" -p no:cacheprovider 2>&1 | tail -3 | tee -a $OUT/pytest_lbs.txt
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r03m; mkdir -p $OUT; cd $R
+for cfg in "MHMR_STAGGER_PCT=100" "MHMR_STAGGER_PCT=50" "MHMR_STAGGER_PCT=0" "MHMR_STAGGER_PCT=100" "MHMR_STAGGER_PCT=50" "MHMR_STAGGER_PCT=25"; do
+  echo "$cfg: $(env $cfg python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline_attention']['achieved'])")" | tee -a $OUT/ab_stagger.txt
+done
