@@ -58,4 +58,8 @@ for name, N, K, epi, lo in shapes:
     # do the workgroups hit their epilogues together?  spread of the epilogue start of tile r over workgroups
     sp = [t[:, r, 2].max() - t[:, r, 2].min() for r in range(ntile)]
     print(f"   spread over workgroups of the epilogue start, per tile round: {' '.join(f'{x:.1f}' for x in sp[:16])}")
+    tot = t[:, -1, 4] - t[:, 0, 0].min()                       # when each workgroup finished, since the first start
+    xcd = np.arange(256) & 7
+    print(f"   workgroup finish times: mean {tot.mean():.1f}, max {tot.max():.1f} (a perfect tile queue would end near mean + half a tile = {tot.mean() + 0.5 * np.median(tile):.1f});"
+          f" per XCD mean: {' '.join(f'{tot[xcd == x].mean():.0f}' for x in range(8))}")
     del A, W, out
