@@ -174,7 +174,7 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
     // patch rows only (GemmArgs::img_rows: exact tile rounds) and the B class rows go through the skinny kernel (vit_cls.hip);
     // otherwise one GEMM covers all B * Tp rows.  MHMR_ROWMAP=0 forces the latter (A/B measurements).  Everything is launched on the
     // caller's stream: the call is re-entrant across streams and capturable.
-    static const bool rowmap_env = !(getenv("MHMR_ROWMAP") && atoi(getenv("MHMR_ROWMAP")) == 0);
+    static const bool rowmap_env = !(getenv("MHMR_ROWMAP") && atoi(getenv("MHMR_ROWMAP")) == 0) && !getenv("MHMR_GEMM128");
     const bool rowmap = rowmap_env && C % 256 == 0 && N % 256 == 0 && (uint64_t)M * (uint64_t)C * 4u < (1ull << 32);
     const int Mg = rowmap ? B * N : M, ir = rowmap ? N : 0, is = rowmap ? Tp : 0;
     const size_t esz = 2;

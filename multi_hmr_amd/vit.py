@@ -47,7 +47,8 @@ def fold_eligible(C: int, N: int) -> bool:
     """The LayerNorm fold (csrc/gemm256.hip, GemmArgs::pstats / rowstats) needs the token-row map: every block linear on the 256x256
     kernel.  MHMR_LNFOLD=0 / MHMR_ROWMAP=0 switch it off (A/B measurements)."""
     import os
-    return (os.environ.get("MHMR_LNFOLD", "1") != "0" and os.environ.get("MHMR_ROWMAP", "1") != "0" and C % 256 == 0 and N % 256 == 0)
+    return (os.environ.get("MHMR_LNFOLD", "1") != "0" and os.environ.get("MHMR_ROWMAP", "1") != "0" and "MHMR_GEMM128" not in os.environ and
+            C % 256 == 0 and N % 256 == 0)
 
 
 def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = None, lnfold: bool | None = None) -> dict:
@@ -132,7 +133,7 @@ def row_map(P: dict, B: int) -> bool:
     class rows through csrc/vit_cls.hip) when an image's patch rows are whole 256-row tiles of the 256x256 kernel."""
     import os
     T = P["T"]
-    return (os.environ.get("MHMR_ROWMAP", "1") != "0" and P["C"] % 256 == 0 and (T - 1) % 256 == 0 and
+    return (os.environ.get("MHMR_ROWMAP", "1") != "0" and "MHMR_GEMM128" not in os.environ and P["C"] % 256 == 0 and (T - 1) % 256 == 0 and
             B * roundup(T, 64) * P["C"] * 4 < 2 ** 32)
 
 
@@ -141,8 +142,12 @@ def padded_tokens(P: dict, B: int) -> int:
     tile, the V^T row granularity) when every linear of the encoder stays on the 256x256 kernel -- the GEMMs cover the patch rows only
     (row_map), or embed_dim and B * Tp are multiples of 256; otherwise a multiple of 128, the row tile of the 128x128 kernel.
     896^2: 4160 instead of 4224 rows per image."""
+    import os
     t64, t128 = roundup(P["T"], 64), roundup(P["T"], 128)
-    return t64 if (row_map(P, B) or (P["C"] % 256 == 0 and (B * t64) % 256 == 0)) else t128
+    # the predicate of csrc/gemm256.hip mhmr_gemm256_eligible for the residual GEMMs over all B * Tp rows (32-bit residual offsets),
+    # and the switch that forces the 128x128 kernel everywhere
+    all_rows_256 = (P["C"] % 256 == 0 and (B * t64) % 256 == 0 and B * t64 * P["C"] * 4 < 2 ** 32 and "MHMR_GEMM128" not in os.environ)
+    return t64 if (row_map(P, B) and "MHMR_GEMM128" not in os.environ) or all_rows_256 else t128
 
 
 class WorkspaceCache:

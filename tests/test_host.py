@@ -151,3 +151,8 @@ def test_token_rows_per_image_rule(monkeypatch):
     monkeypatch.setenv("MHMR_ROWMAP", "0")                                # the A/B switch of csrc/capi.hip
     assert vit.padded_tokens(L, 32) == 4160 and vit.padded_tokens(L, 1) == 4224 and vit.padded_tokens(L, 6) == 4224
     assert vit.padded_tokens({"C": 1024, "T": 257}, 2) == 384
+    # beyond the 32-bit residual offsets of the 256x256 kernel the residual GEMMs fall back to the 128x128 kernel: its row tile decides
+    monkeypatch.delenv("MHMR_ROWMAP")
+    assert vit.padded_tokens(L, 512) == 4224 and vit.padded_tokens({"C": 1024, "T": 8465}, 128) == 8576
+    monkeypatch.setenv("MHMR_GEMM128", "1")                               # the switch that forces the 128x128 kernel everywhere
+    assert vit.padded_tokens(L, 32) == 4224 and not vit.row_map(L, 32) and not vit.fold_eligible(1024, 4096)
