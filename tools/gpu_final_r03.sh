@@ -9,6 +9,8 @@ export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; tail -4 $OUT/pytest_gpu.log > $OUT/summary.txt
 grep -E "^(FAILED|ERROR)" $OUT/pytest_gpu.log >> $OUT/summary.txt
 cp gpurun_out/parity_fullsize.json $OUT/ 2>/dev/null
+# the 128x128 kernel everywhere (debug switch): the ViT-L golden must still hold
+MHMR_GEMM128=1 timeout 600 python -m pytest tests/test_gpu_model.py -q -k "golden and vitl_224" -p no:cacheprovider 2>&1 | tail -2 >> $OUT/summary.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" >> $OUT/summary.txt 2>&1
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 python - >> $OUT/summary.txt <<'PY'
