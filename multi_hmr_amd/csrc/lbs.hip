@@ -303,7 +303,7 @@ constexpr int LBS_NC = 10, LBS_NL = 2;                 // compute waves (one per
 constexpr int LBS_KB = 512;                            // padded blend depth (486 pose + betas + 10 expression <= 512)
 constexpr int LBS_NX = 72;                             // extra joints 55..126 (virtual vertices in the tiles from c.Vl on)
 constexpr int LBS_NS = LBS_KB / 32;                    // k steps of 32
-constexpr int LBS_NE = 8, LBS_RING = 3;                // k eighths (2 steps each), LDS ring slots
+constexpr int LBS_NE = 8, LBS_RING = 3;                // k eighths (2 steps each), LDS ring slots (4 slots: measured no faster at 1 / 20 / 160 persons)
 constexpr int LBS_ROW = LBS_TV * 8 * 2;                // bytes of one (k block, part, axis) row of the tile: 48 vertices x 8 k x f16
 constexpr int LBS_EBYTES = (LBS_KB / 8 / LBS_NE) * 6 * LBS_ROW;       // one eighth of the tile's slice: 36 KiB
 constexpr int LBS_EOPS = LBS_EBYTES / 1024 / LBS_NL;                  // 1-KiB copies per loader wave per eighth

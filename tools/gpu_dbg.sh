@@ -1,4 +1,3 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r03j; mkdir -p $OUT; cd $R
-timeout 300 python tools/gemm_timeline.py f16 2>&1 | grep -v amdgpu.ids > $OUT/gemm_timeline_b.txt
-grep "==\|finish\|tile period" $OUT/gemm_timeline_b.txt | cut -c1-260
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r03n; mkdir -p $OUT; cd $R
+for P in 1 20 160; do MHMR_LIB=tools/dbg/libmhmr_stamps.so timeout 120 python tools/lbs_timeline.py $P 2>&1 | grep -v amdgpu.ids | tee -a $OUT/lbs_timeline.txt; done
