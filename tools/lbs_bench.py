@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""SMPL-X layer alone (mhmr_lbs_forward) at P persons: wall per launch of the three kernels + hipEvent time of the vertex kernel."""
+"""SMPL-X layer alone (mhmr_lbs_forward) at P persons: wall per call of the layer (pose kernel + vertex kernel) + hipEvent time of the vertex kernel."""
 import ctypes as C, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
