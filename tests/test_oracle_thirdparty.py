@@ -159,6 +159,64 @@ def test_lbs_one_hot_weights_single_joint(smplx_data):
     assert (out.vertices[0, ~still] - rest.vertices[0, ~still]).abs().max() > 1e-3
 
 
+def _lbs_loops(data, pose55, betas, expr):
+    """SMPL-X forward written a second time, differently on purpose: numpy float64, scipy's Rodrigues, the kinematic chain as a
+    recursion over 4x4 matrices, the skinning as an explicit sum over (vertex, joint) pairs with non-zero weight.  One body."""
+    from scipy.spatial.transform import Rotation
+    v_t = np.asarray(data["v_template"], np.float64)
+    sd = np.asarray(data["shapedirs"], np.float64)
+    dirs = np.concatenate([sd[:, :, :10], sd[:, :, 300:310]], -1)                       # [V,3,20]
+    coef = np.concatenate([betas, expr]).astype(np.float64)
+    v_shaped = v_t + dirs @ coef
+    J = np.asarray(data["J_regressor"], np.float64) @ v_shaped                          # rest joints [55,3]
+    R = Rotation.from_rotvec(pose55.astype(np.float64)).as_matrix()                     # [55,3,3]
+    pd = np.asarray(data["posedirs"], np.float64)                                       # [V,3,486]
+    feat = np.concatenate([(R[j] - np.eye(3)).reshape(-1) for j in range(1, 55)])       # joint-major, row-major 3x3
+    v_posed = v_shaped + pd @ feat
+    parents = np.asarray(data["kintree_table"])[0].astype(int)
+
+    def world(j):                                                                        # 4x4 world transform of joint j (rest -> posed)
+        T = np.eye(4)
+        T[:3, :3] = R[j]
+        if j == 0:
+            T[:3, 3] = J[0]
+            return T
+        T[:3, 3] = J[j] - J[parents[j]]
+        return world(int(parents[j])) @ T
+
+    G = [world(j) for j in range(55)]
+    A = []
+    for j in range(55):                                                                  # remove the rest pose: x -> G_j (x - J_j)
+        Tj = G[j].copy()
+        Tj[:3, 3] = G[j][:3, 3] - G[j][:3, :3] @ J[j]
+        A.append(Tj)
+    W = np.asarray(data["weights"], np.float64)
+    verts = np.zeros_like(v_posed)
+    for v in range(0, v_posed.shape[0], 1):
+        for j in np.nonzero(W[v])[0]:
+            verts[v] += W[v, j] * (A[j][:3, :3] @ v_posed[v] + A[j][:3, 3])
+    joints = np.stack([G[j][:3, 3] for j in range(55)])
+    return verts, joints
+
+
+def test_lbs_restatement_matches_a_second_independent_implementation(smplx_data):
+    """oracle/smplx_ref.py (the restated smplx.lbs, batched torch fp32) against the loop implementation above (numpy fp64, scipy
+    Rodrigues): vertices, the 55 posed joints, the 21 picked vertices and the 51 barycentric landmarks."""
+    bm = _bm(smplx_data)
+    g = torch.Generator().manual_seed(11)
+    pose = 0.4 * torch.randn(1, 55, 3, generator=g)
+    betas, expr = torch.randn(1, 10, generator=g), torch.randn(1, 10, generator=g)
+    out = _call(bm, pose, betas, expr)
+    verts, joints = _lbs_loops(smplx_data, pose[0].numpy(), betas[0].numpy(), expr[0].numpy())
+    assert np.abs(out.vertices[0].double().numpy() - verts).max() < 5e-6
+    assert np.abs(out.joints[0, :55].double().numpy() - joints).max() < 5e-6
+    faces = np.asarray(smplx_data["f"]).astype(np.int64)
+    lf, lb = np.asarray(smplx_data["lmk_faces_idx"]).astype(np.int64), np.asarray(smplx_data["lmk_bary_coords"], np.float64)
+    lmk = np.einsum("lk,lkc->lc", lb, verts[faces[lf]])
+    assert np.abs(out.joints[0, 76:].double().numpy() - lmk).max() < 5e-6
+    assert np.abs(out.joints[0, 55:76].double().numpy() - verts[list(smplx_ref.SMPLX_EXTRA_JOINT_VERTS)]).max() < 5e-6
+
+
 def test_smplx_tables_of_oracle_and_product_agree():
     """oracle/smplx_ref.py and multi_hmr_amd/constants.py each hold their own literal copy of the smplx vertex ids / joint names
     (so that a wrong id on one side is a parity failure); this is the one place where the two are compared."""
