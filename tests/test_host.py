@@ -156,3 +156,89 @@ def test_token_rows_per_image_rule(monkeypatch):
     assert vit.padded_tokens(L, 512) == 4224 and vit.padded_tokens({"C": 1024, "T": 8465}, 128) == 8576
     monkeypatch.setenv("MHMR_GEMM128", "1")                               # the switch that forces the 128x128 kernel everywhere
     assert vit.padded_tokens(L, 32) == 4224 and not vit.row_map(L, 32) and not vit.fold_eligible(1024, 4096)
+
+
+def test_low_half_weight_split_and_spec_parser():
+    """vit.hi_lo: [W_hi | W_lo] reproduces the fp32 weight to 2^-22 relative (f16) where one rounding leaves 2^-11; vit.parse_wlo."""
+    import torch
+    from multi_hmr_amd import vit
+    torch.manual_seed(3)
+    w = torch.randn(64, 128) / 11.0
+    wd = w.double()
+    for tdt, bits, floor in ((torch.float16, 11, 2.0 ** -25), (torch.bfloat16, 8, 0.0)):      # (f16: the subnormal step where W_lo underflows)
+        p = vit.hi_lo(w, tdt)
+        assert p.shape == (64, 256) and p.dtype == tdt
+        hi, lo = p[:, :128].double(), p[:, 128:].double()
+        assert bool(((hi - wd).abs() <= 2.0 ** -bits * wd.abs() + floor).all()) and float((hi - wd).abs().max()) > 2.0 ** -(bits + 3) * float(wd.abs().max())
+        assert bool(((hi + lo - wd).abs() <= 2.0 ** -(2 * bits) * wd.abs() + floor).all())
+    assert vit.parse_wlo("v+proj@0-11", 24) == {i: {"v", "proj"} for i in range(12)}
+    assert vit.parse_wlo("v+proj@0-11", 4) == {i: {"v", "proj"} for i in range(4)}          # clipped to the depth
+    assert vit.parse_wlo("proj@2,v@2-3", 24) == {2: {"proj", "v"}, 3: {"v"}}
+    assert vit.parse_wlo("", 24) == {} and vit.parse_wlo(None, 24) == {}
+    assert vit.parse_wlo("v", 3) == {0: {"v"}, 1: {"v"}, 2: {"v"}}
+    with pytest.raises(ValueError):
+        vit.parse_wlo("fc1@0-3", 24)
+
+
+def test_layernorm_fold_packing_is_the_same_linear_map():
+    """vit.pack_encoder(lnfold=True) on the CPU: for a folded linear, rstd (x . W'^T - mean colsum) + b' computed in fp64 from the PACKED
+    tensors equals Linear(LayerNorm(x)) up to the 16-bit rounding of W' (reference blocks/dinov2.py -> hub Block: norm1 -> attn.qkv,
+    norm2 -> mlp.fc1); block 0's norm1 is not folded; the V rows with a low half carry [W'_hi | W'_lo] and their colsum counts both."""
+    import ctypes as C
+    import torch
+    from oracle import dinov2_ref
+    from multi_hmr_amd import vit
+    torch.manual_seed(5)
+    enc = dinov2_ref.DinoVisionTransformer(embed_dim=256, depth=3, num_heads=4).double()
+    for b in enc.blocks:                                             # non-trivial LayerNorm parameters
+        for n in (b.norm1, b.norm2):
+            n.weight.data = 1.0 + 0.3 * torch.randn_like(n.weight)
+            n.bias.data = 0.2 * torch.randn_like(n.bias)
+    P = vit.pack_encoder(enc.float(), 224, "f16", torch.device("cpu"), wlo="v@1", lnfold=True)
+    blocks = P["vit"]["blocks"]
+    assert [blocks[i].flags for i in range(3)] == [2, 3, 3]
+    torch.set_grad_enabled(False)
+    by_ptr = {t.data_ptr(): t for t in P["keep"]}
+    x = torch.randn(7, 256, dtype=torch.float64) * 2 + 0.3
+    mean, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+    rstd = (var + 1e-6).rsqrt()
+    for i in (1, 2):
+        b = enc.blocks[i].double()
+        for w_ptr, b_ptr, cs_ptr, lin, norm in ((blocks[i].qkv_w, blocks[i].qkv_b, blocks[i].qkv_colsum, b.attn.qkv, b.norm1),
+                                                (blocks[i].fc1_w, blocks[i].fc1_b, blocks[i].fc1_colsum, b.mlp.fc1, b.norm2)):
+            W, bias, cs = by_ptr[w_ptr].double(), by_ptr[b_ptr].double(), by_ptr[cs_ptr].double()
+            want = lin(norm(x))
+            got = rstd * (x @ W.T - mean * cs[None, :]) + bias[None, :]
+            rows = slice(0, 512) if lin is b.attn.qkv and i == 1 else slice(None)      # block 1's V rows live in v_w2 (low-half pass)
+            err = float((got[:, rows] - want[:, rows]).abs().max() / want.abs().max())
+            assert err < 2e-3, (i, err)                                               # one f16 rounding of W'
+    v2, cs = by_ptr[blocks[1].v_w2].double(), by_ptr[blocks[1].qkv_colsum].double()[512:]
+    assert v2.shape == (256, 512) and torch.allclose(cs, v2.sum(1), atol=1e-6)
+    b = enc.blocks[1].double()
+    want = b.attn.qkv(b.norm1(x))[:, 512:]
+    got = rstd * (torch.cat([x, x], 1) @ v2.T - mean * cs[None, :]) + by_ptr[blocks[1].qkv_b].double()[None, 512:]
+    assert float((got - want).abs().max() / want.abs().max()) < 2e-6                   # hi + lo: 22 bits
+    torch.set_grad_enabled(True)
+
+
+def test_extra_joint_tiles_of_the_packed_body_model(smplx_data):
+    """packing.pack_smplx: the 72 extra joints as virtual vertices behind the real ones -- extra joint e = 16 t + i owns column i of the
+    three 16-vertex blocks of tile t, as copies of its corner vertices' columns; picked vertices get the weights (1, 0, 0)."""
+    from multi_hmr_amd import packing, constants
+    pk = packing.pack_smplx(smplx_data, 10, "cpu")
+    V, Vl, Vp = pk["V"], pk["Vl"], pk["Vp"]
+    assert Vl == packing.roundup(V, 48) and Vp == Vl + 5 * 48 and pk["basis16"].shape[0] == Vp // 48
+    b16, s16, vt = pk["basis16"].numpy(), pk["skin16"].numpy(), pk["vtemp"].numpy()
+    faces = np.asarray(smplx_data["f"]).astype(np.int64)
+    corners = np.concatenate([np.repeat(np.asarray(constants.SMPLX_EXTRA_JOINT_VERTS)[:, None], 3, 1),
+                              faces[np.asarray(smplx_data["lmk_faces_idx"]).astype(np.int64)]], 0)
+    assert corners.shape == (72, 3)
+    for e in range(72):
+        for k in range(3):
+            vv, src = Vl + 48 * (e // 16) + 16 * k + e % 16, int(corners[e, k])
+            assert np.array_equal(b16[vv // 48][..., vv % 48, :], b16[src // 48][..., src % 48, :])
+            assert np.array_equal(s16[vv // 48][..., vv % 48, :], s16[src // 48][..., src % 48, :]) and np.array_equal(vt[:, vv], vt[:, src])
+    xb = pk["xbary"].numpy()
+    assert np.array_equal(xb[:21], np.tile([[1.0, 0.0, 0.0]], (21, 1))) and np.allclose(xb[21:], np.asarray(smplx_data["lmk_bary_coords"]))
+    unused = [Vl + 48 * 4 + 16 * k + i for k in range(3) for i in range(8, 16)]           # slots 72..79 of the fifth tile
+    assert all(not b16[v // 48][..., v % 48, :].any() for v in unused)
