@@ -6,7 +6,7 @@ usage: tools/pmc_wait.py <counter_collection.csv> > profiles/rNN_attention_wait_
 import collections, csv, json, re, sys
 acc = collections.OrderedDict()
 for r in csv.DictReader(open(sys.argv[1])):
-    m = re.search(r"(attn_kernel<[^>]*>|gemm256_kernel<\d, \d>|lbs_vertex_kernel)", r["Kernel_Name"])
+    m = re.search(r"(attn_kernel<[^>]*>|gemm256_kernel<[^>]*>|cls_linear_kernel<[^>]*>|lbs_vertex_kernel)", r["Kernel_Name"])
     if m:
         acc.setdefault(m.group(1), collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
