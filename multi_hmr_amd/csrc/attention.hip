@@ -248,20 +248,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
                 m_ref = mt;
             }
         }
-        // ---- p = exp2(s - m_ref); two independent partial sums (one serial chain of 32 adds would pace the wave) ----
+        // ---- p = exp2(s - m_ref) ----
+        // The row sum is taken from the ROUNDED values the PV product multiplies (numerator and denominator of the softmax then see the
+        // same p), two per instruction: v_dot2 of each packed pair against (1, 1), in two independent chains -- 16 VALU instructions per
+        // tile instead of 34 adds; the kernel is VALU-bound.  Measured against fp32 adds on one box: 1036-1039 vs
+        // 1034-1035 TF/s alone, 1007-1013 vs 1001 TF/s inside the forward (f16), 1105 vs 1091 alone (bf16); profiles/r03_attention_rowsum_dot2.txt.
         float psum0 = 0.f, psum1 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p0 = __builtin_amdgcn_exp2f(s[0][r]);
-            const float p1 = __builtin_amdgcn_exp2f(s[1][r]);
-            s[0][r] = p0;
-            s[1][r] = p1;
-            psum0 += p0;
-            psum1 += p1;
+            s[0][r] = __builtin_amdgcn_exp2f(s[0][r]);
+            s[1][r] = __builtin_amdgcn_exp2f(s[1][r]);
         }
-        const float psum = psum0 + psum1;
-        l_run += psum;
-        if constexpr (MODE == 3) bad |= !(psum <= limit);     // all p > 0: a lane sum <= limit proves every p finite in 16 bits
 
         // ---- O^T += V^T . P^T ----
         __builtin_amdgcn_s_setprio(1);
@@ -270,11 +267,23 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
             V8 pf;
 #pragma unroll
             for (int e = 0; e < 8; ++e) pf[e] = (Tt)s[st >> 1][8 * (st & 1) + e];
+            {
+                const u32x4 pw = __builtin_bit_cast(u32x4, pf);
+                psum0 = Op<DT>::pair_sum(pw[0], psum0);
+                psum1 = Op<DT>::pair_sum(pw[1], psum1);
+                psum0 = Op<DT>::pair_sum(pw[2], psum0);
+                psum1 = Op<DT>::pair_sum(pw[3], psum1);
+            }
 #pragma unroll
             for (int ds = 0; ds < 2; ++ds) {
                 const V8 vf = *(const V8*)(sv + (32 * ds + l31) * 128 + (((2 * st + hi) ^ fsw) * 16));
                 o[ds] = Op<DT>::mfma32(vf, pf, o[ds]);
             }
+        }
+        {
+            const float psum = psum0 + psum1;
+            l_run += psum;
+            if constexpr (MODE == 3) bad |= !(psum <= limit);     // all p > 0: a lane sum <= limit proves every p finite in 16 bits
         }
         __builtin_amdgcn_s_setprio(0);
     }

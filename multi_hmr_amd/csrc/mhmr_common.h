@@ -54,6 +54,10 @@ template <> struct Op<MHMR_DT_BF16> {
     static __device__ __forceinline__ f32x4 mfma16(V8 a, V8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ float pair_sum(uint32_t packed, float acc) {
+        asm("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(packed), "s"(0x3F803F80u));
+        return acc;
+    }
 };
 template <> struct Op<MHMR_DT_F16> {
     typedef _Float16 T;
@@ -65,6 +69,11 @@ template <> struct Op<MHMR_DT_F16> {
     }
     static __device__ __forceinline__ f32x4 mfma16(V8 a, V8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    // acc + lo + hi of one packed pair (v_dot2_f32_f16 against (1, 1)): two exact products, fp32 accumulation
+    static __device__ __forceinline__ float pair_sum(uint32_t packed, float acc) {
+        asm("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(packed), "s"(0x3C003C00u));
+        return acc;
     }
 };
 
