@@ -93,16 +93,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // GELU for 16-bit outputs.  x Phi(x) = max(x, 0) - |x| erfc(|x| / sqrt 2) / 2 (erf is odd: no sign select), erfc by
-// Abramowitz-Stegun 7.1.25 (three terms): |abs err on gelu| < 2.6e-5, 40x below the f16 rounding of the stored value, and 12
+// Abramowitz-Stegun 7.1.25 (three terms): |abs err on gelu| < 2.6e-5, 40x below the f16 rounding of the stored value, and 11
 // VALU (2 transcendental) per element instead of 18 for the five-term 7.1.26 with a select or ~40 for erff -- the fc1
 // epilogue's arithmetic was 4 us of its 13.5 us per 256x256 tile.
 __device__ __forceinline__ float gelu_fast(float x) {
     const float ax = fabsf(x);
     const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(ax, 0.47047f * 0.70710678118654752440f, 1.0f));
-    const float p = t * __builtin_fmaf(t, __builtin_fmaf(t, 0.7478556f, -0.0958798f), 0.3480242f);
+    // -erfc / 2: the factor -1/2 of the last step lives in the three coefficients (one VALU instruction less per element)
+    const float p = t * __builtin_fmaf(t, __builtin_fmaf(t, -0.5f * 0.7478556f, 0.5f * 0.0958798f), -0.5f * 0.3480242f);
     const float u = ax * 0.84932180028801904272f;                 // sqrt(log2(e) / 2): exp(-z^2) = exp2(-u^2)
-    const float q = p * __builtin_amdgcn_exp2f(-(u * u));         // erfc(|x| / sqrt 2)
-    return __builtin_fmaf(ax * q, -0.5f, fmaxf(x, 0.f));
+    const float q = p * __builtin_amdgcn_exp2f(-(u * u));         // -erfc(|x| / sqrt 2) / 2
+    return __builtin_fmaf(ax, q, fmaxf(x, 0.f));
 }
 
 // XCD-aware remap of a linear workgroup id: the dispatcher places block b on XCD b % 8 (speed only, never
