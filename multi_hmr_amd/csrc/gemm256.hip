@@ -192,9 +192,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         const uint64_t t0 = wall_clock64(), dl = (uint64_t)g.stagger_ticks * (uint64_t)(first * 4 / G);
         while (wall_clock64() - t0 < dl) __builtin_amdgcn_s_sleep(32);
     }
-    // this workgroup's tiles: one per full round, and the tiles of the last, partial round go to the LOWEST block
-    // indices (b < ntiles % G): when another persistent launch is draining beside this one, the workgroups dispatched first are
-    // then the ones with the extra tile
+    // this workgroup's tiles: one per full round, and the tiles of the last, partial round (none under the token-row map) go to the
+    // LOWEST block indices (b < ntiles % G): the workgroups dispatched first are then the ones with the extra tile
     const int full = ntiles / G, nmine = full + (b < ntiles - full * G ? 1 : 0);
     // (walking the rounds of qk / v / fc1 downwards, so that they start with the rows the residual GEMM before them wrote last -- still in
     // the Infinity Cache -- measured +0.1 %: not kept)
