@@ -1,0 +1,340 @@
+// Prototype (NOT part of libmhmr.so): the 256x256x64 GEMM tile with FOUR waves per workgroup, one per SIMD, each owning a 128x128 wave tile
+// (64 accumulators of v_mfma_f32_16x16x32 = 256 accumulator registers, which the compiler keeps in AccVGPRs at one wave per SIMD), against
+// csrc/gemm256.hip's eight waves of 128x64.  Per k tile a CU then issues 128 fragment reads (ds_read_b128) instead of 192 for the same 512
+// MFMAs, the fragments of the next k step are requested before the current step's MFMAs, and one barrier per k tile hands the ring over.
+// Question it answers: does the main loop get closer to the MFMA-bound 1.145 us per 256x256x64 k tile (at 1.8 GHz) than the 1.40-1.47 us the
+// shipped kernel needs when every operand is an L2 hit?
+//   C[m][n] = sum_k A[m][k] W[n][k]  (f16 operands, fp32 accumulate, f16 out), persistent tile walk, plain epilogue (direct stores).
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -DMHMR_NO_SLP -DASM_MFMA -DV3 -I ../../multi_hmr_amd/csrc -o gemm4w_v3 gemm4w.hip
+// Variants (macros): none = fragments of a k step read in one burst, builtin MFMA (the compiler shuffles 26 accumulator tuples per k tile through
+// a spare AccVGPR tuple: 104 v_accvgpr_mov per k tile); ASM_MFMA = accumulators pinned by inline asm; INTERLEAVE = the copies / reads of phase B
+// between its MFMA groups; V3 = every non-MFMA instruction between MFMA groups, barrier behind group 5 of phase A; EARLY_DMA = all 16 copies right
+// behind the barrier.  Measured on one MI355X (profiles/r03_gemm4w_prototype.txt), microseconds per 256x256x64 k tile with every operand an L2 hit:
+// none 1.93, ASM_MFMA 1.78, + INTERLEAVE 1.56, V3 1.46-1.47, V3 + EARLY_DMA 1.61 -- the shipped eight-wave kernel: 1.40-1.47.  Two structurally
+// different main loops end at the same 1.45 us = 0.59 of the 2.4 GHz MFMA peak: the power-limited rate of this chip on random f16 data.
+#include "mhmr_common.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace {
+
+typedef _Float16 T;
+typedef f16x8 V8;
+typedef f16x4 V4;
+constexpr int HT = 16384;                 // one half-tile slot: 128 rows x 64 k x 2 B
+constexpr int BUF = 4 * HT;               // P0 | P1 | Q0 | Q1 of one k tile
+constexpr int LDS_BYTES = 2 * BUF;        // two k tiles
+
+#ifdef ASM_MFMA      // accumulator pinned in an AccVGPR tuple, result in place (the compiler otherwise shuffles 26 tuples per k tile through a spare one)
+__device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    return c;
+}
+#else
+__device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+#endif
+
+// stamps: [block][tile][2] wall clock at the start / end of the tile's k loop (wave 0)
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4w_kernel(const T* __restrict__ A, const T* __restrict__ W,
+                                                                                                    T* __restrict__ C, int M, int N, int K, int same,
+                                                                                                    unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = w >> 1, wq = w & 1;            // this wave's P half (128 output columns n) and Q half (128 output rows m)
+    const int g4 = lane >> 4, l15 = lane & 15;
+    const int nbn = N / 256, ntiles = (M / 256) * nbn, nt = K / 64;
+    const int G = gridDim.x, b = blockIdx.x;
+    const int first = (G & 7) == 0 ? (b & 7) * (G >> 3) + (b >> 3) : b;       // XCD x owns a contiguous run of tiles per round
+
+    // DMA: a half-tile = 4 passes of 32 rows; lane-linear LDS image, XOR swizzle on the source chunk
+    const int srow = tid >> 3, schunk = (tid & 7) ^ ((tid >> 4) & 7);
+    const uint32_t lane_off = (uint32_t)srow * (uint32_t)K + (uint32_t)(schunk * 8);
+    auto dma = [&](const T* base, int half, int kt, int lds_off) {
+        const T* src = base + (size_t)(128 * half) * K + (size_t)kt * 64 + lane_off;
+        char* d = smem + lds_off + w * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(src + (size_t)(32 * i) * K, d + 4096 * i);
+    };
+    auto dma_tile = [&](const T* pb, const T* qb, int kt, int buf) {       // 16 copies per wave
+        dma(pb, 0, kt, buf * BUF);
+        dma(pb, 1, kt, buf * BUF + HT);
+        dma(qb, 0, kt, buf * BUF + 2 * HT);
+        dma(qb, 1, kt, buf * BUF + 3 * HT);
+    };
+
+    const int fsw = l15 >> 1;
+    int co[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) co[ks] = ((4 * ks + g4) ^ fsw) * 16;
+    const int p_off = wp * HT + l15 * 128, q_off = (2 + wq) * HT + l15 * 128;
+
+    f32x4 acc[8][8];
+    V8 PF[2][8], QF[2][8];             // [k step parity][16-row sub-tile]
+    auto rd = [&](int set, int buf, int ks) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            PF[set][i] = *(const V8*)(smem + buf * BUF + p_off + i * 2048 + co[ks]);
+            QF[set][i] = *(const V8*)(smem + buf * BUF + q_off + i * 2048 + co[ks]);
+        }
+    };
+    auto mm = [&](int set) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = mfma(PF[set][i], QF[set][j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define SYNC()                       \
+    __builtin_amdgcn_s_barrier();    \
+    __builtin_amdgcn_sched_barrier(0)
+
+    const int full = ntiles / G, nmine = full + (b < ntiles - full * G ? 1 : 0);
+    auto tile_of = [&](int r) { return r >= full ? full * G + b : first + r * G; };
+    auto bases = [&](int tix, const T*& pb, const T*& qb, int& n0, int& m0) {
+        if (same) tix = 0;
+        n0 = (tix % nbn) * 256;
+        m0 = (tix / nbn) * 256;
+        pb = W + (size_t)n0 * K;
+        qb = A + (size_t)m0 * K;
+    };
+    if (nmine == 0) return;
+    const T *pb, *qb, *pn, *qn;
+    int n0, m0, n0n, m0n;
+    bases(tile_of(0), pb, qb, n0, m0);
+    dma_tile(pb, qb, 0, 0);
+    dma_tile(pb, qb, 1, 1);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // k tile 0 has landed (16 younger copies: k tile 1)
+    SYNC();
+    rd(0, 0, 0);
+    for (int r = 0; r < nmine; ++r) {
+        const bool has_next = r + 1 < nmine;
+        if (has_next) bases(tile_of(r + 1), pn, qn, n0n, m0n);
+        else { pn = pb; qn = qb; n0n = n0; m0n = m0; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef ASM_MFMA
+        asm volatile("s_nop 7" ::: "memory");
+#endif
+        if (stamps && tid == 0 && r < 64) stamps[((size_t)b * 64 + r) * 2] = wall_clock64();
+#ifdef V3
+        // One wave per SIMD: every instruction that is not an MFMA is issued BETWEEN MFMAs.  Per k tile: phase A = 8 groups of 8 MFMAs on
+        // k step 0 (fragment set 0) with the 16 fragment reads of k step 1 (set 1) behind groups 0..3; the landing wait + the barrier that
+        // hands the ring over sit behind group 5 (this wave's reads of k tile t are long done, k tile t + 1 was requested a phase ago);
+        // phase B = 8 groups on k step 1 with the 16 copies of k tile t + 2 and the 16 reads of k tile t + 1's step 0 behind them
+        // (Q fragments first: the next phase A needs all of them at its first group, the P fragments one group at a time).
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            const int t2 = t + 2;
+            const T* p2 = t2 < nt ? pb : pn;
+            const T* q2 = t2 < nt ? qb : qn;
+            const int k2 = t2 < nt ? t2 : (has_next ? t2 - nt : nt - 1);
+            const char* cur = smem + buf * BUF;
+            const char* nxt = smem + (buf ^ 1) * BUF;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = mfma(PF[0][i], QF[0][j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i < 2) {
+#pragma unroll
+                    for (int q = 4 * i; q < 4 * i + 4; ++q) QF[1][q] = *(const V8*)(cur + q_off + q * 2048 + co[1]);
+                } else if (i < 4) {
+#pragma unroll
+                    for (int q = 4 * (i - 2); q < 4 * (i - 2) + 4; ++q) PF[1][q] = *(const V8*)(cur + p_off + q * 2048 + co[1]);
+                } else if (i == 5) {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+#ifdef EARLY_DMA       // the 16 copies of k tile t + 2 right behind the barrier that frees their buffer: a whole k tile period of lead
+                else if (i >= 6) {
+#pragma unroll
+                    for (int c = 8 * (i - 6); c < 8 * (i - 6) + 8; ++c) {
+                        const int h = c >> 2, ps = c & 3;
+                        const T* base = (h < 2 ? p2 : q2) + (size_t)(128 * (h & 1)) * K + (size_t)k2 * 64 + lane_off;
+                        glds16(base + (size_t)(32 * ps) * K, smem + buf * BUF + h * HT + w * 1024 + 4096 * ps);
+                    }
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = mfma(PF[1][i], QF[1][j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef EARLY_DMA
+#pragma unroll
+                for (int c = 2 * i; c < 2 * i + 2; ++c) {
+                    const int h = c >> 2, ps = c & 3;
+                    const T* base = (h < 2 ? p2 : q2) + (size_t)(128 * (h & 1)) * K + (size_t)k2 * 64 + lane_off;
+                    glds16(base + (size_t)(32 * ps) * K, smem + buf * BUF + h * HT + w * 1024 + 4096 * ps);
+                }
+#endif
+                if (i < 4) {
+                    QF[0][2 * i] = *(const V8*)(nxt + q_off + (2 * i) * 2048 + co[0]);
+                    QF[0][2 * i + 1] = *(const V8*)(nxt + q_off + (2 * i + 1) * 2048 + co[0]);
+                } else {
+                    PF[0][2 * (i - 4)] = *(const V8*)(nxt + p_off + (2 * (i - 4)) * 2048 + co[0]);
+                    PF[0][2 * (i - 4) + 1] = *(const V8*)(nxt + p_off + (2 * (i - 4) + 1) * 2048 + co[0]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#else
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            // k step 0 of k tile t is in PF/QF[0]; request k step 1, multiply step 0
+            rd(1, buf, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(0);
+            __builtin_amdgcn_sched_barrier(0);
+            // k tile t + 1 (requested one iteration ago) has landed when only the ... nothing younger is outstanding: vmcnt(0)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // ... and this wave has every fragment of k tile t in registers
+            SYNC();                                                            // k tile t + 1 visible to all, buffer `buf` free
+            // refill `buf` with k tile t + 2 (past the end of this output tile: the first k tiles of the next one) and fetch k step 0 of
+            // k tile t + 1, both BETWEEN the MFMAs of k step 1 (one wave per SIMD: nothing else would fill the issue gap)
+            {
+                const int t2 = t + 2;
+                const T* p2 = t2 < nt ? pb : pn;
+                const T* q2 = t2 < nt ? qb : qn;
+                const int k2 = t2 < nt ? t2 : (has_next ? t2 - nt : nt - 1);
+#ifdef INTERLEAVE
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[i][j] = mfma(PF[1][i], QF[1][j], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // two of the 16 copies, two of the 16 fragment reads
+                    {
+                        const int c0 = 2 * i;                      // copies c0, c0 + 1: (operand half h = c >> 2, pass = c & 3)
+#pragma unroll
+                        for (int c = c0; c < c0 + 2; ++c) {
+                            const int h = c >> 2, ps = c & 3;
+                            const T* base = (h < 2 ? p2 : q2) + (size_t)(128 * (h & 1)) * K + (size_t)k2 * 64 + lane_off;
+                            glds16(base + (size_t)(32 * ps) * K, smem + buf * BUF + h * HT + w * 1024 + 4096 * ps);
+                        }
+                        PF[0][i] = *(const V8*)(smem + (buf ^ 1) * BUF + p_off + i * 2048 + co[0]);
+                        QF[0][i] = *(const V8*)(smem + (buf ^ 1) * BUF + q_off + i * 2048 + co[0]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_s_setprio(0);
+#else
+                dma_tile(p2, q2, k2, buf);
+                rd(0, buf ^ 1, 0);            // k step 0 of k tile t + 1 (at the end of the tile: of the next tile's k tile 0)
+                __builtin_amdgcn_sched_barrier(0);
+                mm(1);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+        }
+#endif
+        if (stamps && tid == 0 && r < 64) stamps[((size_t)b * 64 + r) * 2 + 1] = wall_clock64();
+#ifdef ASM_MFMA
+        asm volatile("s_nop 15\n s_nop 15" ::: "memory");      // (the compiler does not see the MFMAs inside the asm: the accumulator reads below need their wait states)
+#endif
+        // ---- plain epilogue: lane holds C[m = m0 + 128 wq + 16 j + l15][n = n0 + 128 wp + 16 i + 4 g4 + 0..3] ----
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                V4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (T)acc[i][j][e];
+                *(V4*)(C + (size_t)(m0 + 128 * wq + 16 * j + l15) * N + n0 + 128 * wp + 16 * i + 4 * g4) = o;
+            }
+        pb = pn; qb = qn; n0 = n0n; m0 = m0n;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef SYNC
+}
+
+__global__ void ref_kernel(const T* A, const T* W, float* out, int N, int K, int m_lo, int rows) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, m = m_lo + blockIdx.y;
+    if (n >= N || blockIdx.y >= rows) return;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += (float)A[(size_t)m * K + k] * (float)W[(size_t)n * K + k];
+    out[(size_t)blockIdx.y * N + n] = s;
+}
+
+#define CK(x)                                                                    \
+    do {                                                                         \
+        hipError_t e__ = (x);                                                    \
+        if (e__ != hipSuccess) { printf("HIP error %d at %s:%d\n", (int)e__, __FILE__, __LINE__); exit(1); } \
+    } while (0)
+
+void run(int M, int N, int K, int same) {
+    T *A, *W, *C;
+    CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&W, (size_t)N * K * 2)); CK(hipMalloc(&C, (size_t)M * N * 2));
+    {
+        std::vector<T> h((size_t)std::max(M, N) * K);
+        unsigned s = 12345u;
+        auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+        for (size_t i = 0; i < (size_t)M * K; ++i) h[i] = (T)rnd();
+        CK(hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < (size_t)N * K; ++i) h[i] = (T)(rnd() * 0.25f);
+        CK(hipMemcpy(W, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice));
+    }
+    unsigned long long* stamps;
+    CK(hipMalloc(&stamps, 256 * 64 * 2 * 8));
+    CK(hipMemset(stamps, 0, 256 * 64 * 2 * 8));
+    CK(hipFuncSetAttribute((const void*)gemm4w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    const int ntiles = (M / 256) * (N / 256), grid = ntiles < 256 ? ntiles : 256;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm4w_kernel, dim3(grid), dim3(256), LDS_BYTES, 0, A, W, C, M, N, K, same, (unsigned long long*)nullptr);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    const int it = 10;
+    for (int i = 0; i < it; ++i) hipLaunchKernelGGL(gemm4w_kernel, dim3(grid), dim3(256), LDS_BYTES, 0, A, W, C, M, N, K, same, (unsigned long long*)nullptr);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= it;
+    hipLaunchKernelGGL(gemm4w_kernel, dim3(grid), dim3(256), LDS_BYTES, 0, A, W, C, M, N, K, same, stamps);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> st(256 * 64 * 2);
+    CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> kl;
+    const int per = ntiles / grid;
+    for (int b = 0; b < grid; ++b)
+        for (int r = 0; r < per && r < 64; ++r) kl.push_back((double)(st[((size_t)b * 64 + r) * 2 + 1] - st[((size_t)b * 64 + r) * 2]) * 0.01);
+    std::sort(kl.begin(), kl.end());
+    const double med = kl.empty() ? 0 : kl[kl.size() / 2];
+    // correctness on 8 rows spread over the matrix (not with `same`: every tile then writes tile 0's values)
+    double maxerr = 0, maxref = 0;
+    if (!same) {
+        float* ref;
+        CK(hipMalloc(&ref, (size_t)N * 4));
+        std::vector<float> hr(N);
+        std::vector<T> hc(N);
+        for (int m : {0, 1, 255, 256, M / 2 + 37, M - 257, M - 2, M - 1}) {
+            hipLaunchKernelGGL(ref_kernel, dim3((N + 255) / 256, 1), dim3(256), 0, 0, A, W, ref, N, K, m, 1);
+            CK(hipMemcpy(hr.data(), ref, (size_t)N * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hc.data(), C + (size_t)m * N, (size_t)N * 2, hipMemcpyDeviceToHost));
+            for (int n = 0; n < N; ++n) { maxerr = std::max(maxerr, (double)fabsf((float)hc[n] - hr[n])); maxref = std::max(maxref, (double)fabsf(hr[n])); }
+        }
+        CK(hipFree(ref));
+    }
+    printf("M=%d N=%d K=%d same=%d: %8.4f ms  %7.1f TFLOP/s   k loop %6.2f us per tile = %.3f us per k tile (median)   max err %.3g (max |ref| %.3g)\n", M, N, K, same, ms,
+           2.0 * M * N * K / ms / 1e9, med, med / (K / 64), maxerr, maxref);
+    CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C)); CK(hipFree(stamps));
+}
+
+}  // namespace
+
+int main() {
+    run(4096, 4096, 4096, 0);
+    run(131072, 4096, 1024, 0);      // fc1
+    run(131072, 4096, 1024, 1);      // ... every operand an L2 hit
+    run(131072, 1024, 4096, 0);      // fc2
+    run(131072, 2048, 1024, 0);      // qk
+    return 0;
+}
