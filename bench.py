@@ -264,6 +264,7 @@ def main():
         m2 = build_model(args.backbone, S, other, smplx_data, mean_params, dev)
         dt2 = time_steps(lambda: m2(x, idx=idx, K=K, is_training=True), 10, 3, dev)
         result["other_precision"] = {"dtype": other, "value": round(B * 10 / dt2, 2), "unit": "images/s", "ms_per_step": round(1e3 * dt2 / 10, 3),
+                                     "mfma_utilisation_whole_forward": round((gemm_fl + attn_fl) * B * 10 / dt2 / 1e12 / PEAK_MFMA_TFLOPS, 4),
                                      "note": "same kernels; bf16 operands miss the 1e-3 parity contract (tests/test_gpu_parity_fullsize.py)"
                                      if other == "bf16" else "the precision that meets 1e-3 parity"}
         del m2
