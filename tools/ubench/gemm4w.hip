@@ -11,7 +11,8 @@
 // between its MFMA groups; V3 = every non-MFMA instruction between MFMA groups, barrier behind group 5 of phase A; EARLY_DMA = all 16 copies right
 // behind the barrier.  Measured on one MI355X (profiles/r03_gemm4w_prototype.txt), microseconds per 256x256x64 k tile with every operand an L2 hit:
 // none 1.93, ASM_MFMA 1.78, + INTERLEAVE 1.56, V3 1.46-1.47, V3 + EARLY_DMA 1.61 -- the shipped eight-wave kernel: 1.40-1.47.  Two structurally
-// different main loops end at the same 1.45 us = 0.59 of the 2.4 GHz MFMA peak: the power-limited rate of this chip on random f16 data.
+// different main loops end at the same 1.45 us = 0.59 of the 2.4 GHz MFMA peak: the power-limited rate of this chip on random f16 data
+// (`./gemm4w_v3 zero`: the same binary on zero-filled operands runs 1.20 us per k tile).
 #include "mhmr_common.h"
 #include <cstdio>
 #include <cstdlib>
@@ -269,7 +270,7 @@ __global__ void ref_kernel(const T* A, const T* W, float* out, int N, int K, int
         if (e__ != hipSuccess) { printf("HIP error %d at %s:%d\n", (int)e__, __FILE__, __LINE__); exit(1); } \
     } while (0)
 
-void run(int M, int N, int K, int same) {
+void run(int M, int N, int K, int same, int zero = 0) {
     T *A, *W, *C;
     CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&W, (size_t)N * K * 2)); CK(hipMalloc(&C, (size_t)M * N * 2));
     {
@@ -280,6 +281,7 @@ void run(int M, int N, int K, int same) {
         CK(hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice));
         for (size_t i = 0; i < (size_t)N * K; ++i) h[i] = (T)(rnd() * 0.25f);
         CK(hipMemcpy(W, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice));
+        if (zero) { CK(hipMemset(A, 0, (size_t)M * K * 2)); CK(hipMemset(W, 0, (size_t)N * K * 2)); }      // the power-limit check: no toggling operand bits
     }
     unsigned long long* stamps;
     CK(hipMalloc(&stamps, 256 * 64 * 2 * 8));
@@ -323,14 +325,19 @@ void run(int M, int N, int K, int same) {
         }
         CK(hipFree(ref));
     }
-    printf("M=%d N=%d K=%d same=%d: %8.4f ms  %7.1f TFLOP/s   k loop %6.2f us per tile = %.3f us per k tile (median)   max err %.3g (max |ref| %.3g)\n", M, N, K, same, ms,
+    printf("M=%d N=%d K=%d same=%d zero=%d: %8.4f ms  %7.1f TFLOP/s   k loop %6.2f us per tile = %.3f us per k tile (median)   max err %.3g (max |ref| %.3g)\n", M, N, K, same, zero, ms,
            2.0 * M * N * K / ms / 1e9, med, med / (K / 64), maxerr, maxref);
     CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C)); CK(hipFree(stamps));
 }
 
 }  // namespace
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) {          // zero-filled operands against random ones: same instruction stream, different power
+        run(4096, 4096, 4096, 0, 0); run(4096, 4096, 4096, 0, 1);
+        run(131072, 4096, 1024, 1, 0); run(131072, 4096, 1024, 1, 1);
+        return 0;
+    }
     run(4096, 4096, 4096, 0);
     run(131072, 4096, 1024, 0);      // fc1
     run(131072, 4096, 1024, 1);      // ... every operand an L2 hit
