@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define MHMR_VERSION 102   /* 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
+#define MHMR_VERSION 103   /* 103: mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
 
 #define MHMR_OK 0
 #define MHMR_ERR_BAD_ARG (-1)
@@ -44,6 +44,9 @@ extern "C" {
 #define MHMR_ATTN_QSCALE 0.18033688011112042f
 
 int mhmr_version(void);
+/* sha256 prefix (16 hex digits) of the sources + compile flags this library was built from (multi_hmr_amd/_lib.py::source_hash);
+ * "unknown" for a build that did not pass it.  Evidence files (profiles/) are keyed by it. */
+const char* mhmr_source_hash(void);
 
 /* ------------------------------------------------------------------------------------------------------------
  * ViT backbone.  Replaces blocks/dinov2.py:16-26 -> torch.hub DinoVisionTransformer.get_intermediate_layers
@@ -65,7 +68,8 @@ typedef struct {
     const void* v_w2;             /* blocks.i.attn.qkv.weight[2C:3C] as hi | lo, or NULL              */
     const void* proj_w2;          /* blocks.i.attn.proj.weight as hi | lo, or NULL                    */
     /* LayerNorm folded into the consuming linear (used when mhmr_vit_desc.pstats / rowstats are given and the token-row map is on):
-     * flags bit 0: norm1 -> qkv, bit 1: norm2 -> fc1.  A folded linear's weight is W diag(w_ln) (v_w2 likewise), its bias is
+     * flags bit 0: norm1 -> qkv (never for blocks[0]: the patch embedding leaves no row statistics, MHMR_ERR_BAD_ARG), bit 1: norm2 -> fc1;
+     * a set bit needs its *_colsum (MHMR_ERR_BAD_ARG otherwise).  A folded linear's weight is W diag(w_ln) (v_w2 likewise), its bias is
      * b + W b_ln, and *_colsum[n] = sum_k of the ROUNDED folded weight row (hi + lo where there is a low half), fp32. */
     int flags;
     const float* qkv_colsum;      /* [3C] or NULL */
@@ -168,6 +172,18 @@ int mhmr_detect_scores(const void* hid16, int ld, const float* w2, const float* 
 int mhmr_detect_count(const float* scores, int B, int G, int nms_kernel, float thr, int* counts, void* stream);
 int mhmr_detect_write(const float* scores, int B, int G, int nms_kernel, float thr, const int* base, int* det_b,
                       int* det_y, int* det_x, float* det_score, void* stream);
+/* The same into buffers of `cap` entries: detections whose position is >= cap are dropped (the caller compares info[3] of
+ * mhmr_person_groups with cap afterwards). */
+int mhmr_detect_write_cap(const float* scores, int B, int G, int nms_kernel, float thr, const int* base, int* det_b,
+                          int* det_y, int* det_x, float* det_score, int cap, void* stream);
+/* The person set's bookkeeping ON THE DEVICE -- what the reference does on the host after torch.where (model.py:146-151) and in
+ * rebatch / pad_to_max (utils/tensor_manip.py:7-45): per-image counts -> base[b] (exclusive prefix sums, nullable), gstart
+ * [ngroups_cap + 1], chunks [3 * nchunks_cap] as mhmr_hph_forward reads them (unused tail entries = empty groups / count-0 items) and
+ * info[4] = {persons kept = min(total, cap), groups, chunks, total}.  counts [B] from mhmr_detect_count, or NULL: the counts are the
+ * histogram of det_b[0..P) (training hook: the caller's idx, sorted by image).  Sufficient bounds: ngroups_cap = min(B, cap),
+ * nchunks_cap = cap / 8 + min(B, cap).  B <= 8192. */
+int mhmr_person_groups(const int* counts, const int* det_b, int P, int B, int cap, int* base, int* gstart, int ngroups_cap,
+                       int* chunks, int nchunks_cap, int* info, void* stream);
 
 /* Camera embedding.  Replaces Model.embedd_camera (model.py:160-187) + inverse_perspective_projection
  * (utils/camera.py:30-48) + FourierPositionEncoding (blocks/camera_embed.py:9-58).  zK: [B*N, 99] fp32; also
@@ -220,11 +236,16 @@ typedef struct {
     float* kv;      /* [Mctx, 2*inner], Mctx = roundup(B*N, 128) */
     float* dec;     /* [P, Ndec]     */
     int* det_row;   /* [P]           */
+    /* fixed-capacity callers (P = a capacity, the person count known on the device only): DEVICE pointer to the number of real persons
+     * (mhmr_person_groups' info[0]); rows behind it are padding -- computed like persons, never allowed to touch the context operand.
+     * NULL = all P rows are persons. */
+    const int* nvalid;
 } mhmr_hph_desc;
 
 /* Inputs: feat32 [B*N, C], zK [B*N, 99], ctx16 op16 [Mctx, Kc] (features | camera | 0), detections det_{b,y,x}
  * [P] (sorted by (b, y, x)), gstart [ngroups+1] = person offsets of the non-empty images, chunks [nchunks*3] =
- * (image b, first person, count <= 8) cross-attention work items, K [B,3,3].
+ * (image b, first person, count <= 8) cross-attention work items, K [B,3,3].  ngroups / nmax / nchunks size the launches and may be
+ * UPPER BOUNDS when the tables come from mhmr_person_groups (empty groups and count-0 work items return at once).
  * Outputs: offset [P,2], loc [P,2], rotmat [P,53,3,3], rotvec [P,53,3], betas [P,nb], expr [P,10],
  * dist_pp [P] (raw), dist [P] (post-processed).                                                              */
 int mhmr_hph_forward(const mhmr_hph_desc* d, const float* feat32, const float* zK, void* ctx16, const int* det_b,

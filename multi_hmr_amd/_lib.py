@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(CSRC, "libmhmr.so")
 SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "vit_misc.hip", "vit_cls.hip", "hph.hip", "lbs.hip", "preprocess.hip", "evalm.hip", "anny.hip", "capi.hip"]
 HEADERS = ["mhmr_common.h", "mhmr_internal.h", os.path.join("..", "..", "include", "mhmr.h")]
 
-VERSION = 102                       # include/mhmr.h MHMR_VERSION (struct layouts and entry-point semantics)
+VERSION = 103                       # include/mhmr.h MHMR_VERSION (struct layouts and entry-point semantics)
 DT_BF16, DT_F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 EPI_OP16, EPI_OP16_GELU, EPI_OP16_RELU, EPI_RESID, EPI_PATCH, EPI_F32, EPI_VT, EPI_OP16_QK = range(8)
@@ -35,18 +35,44 @@ COMMON_FLAGS = ["-fno-slp-vectorize", "-DMHMR_NO_SLP"]
 EXTRA_FLAGS = {}
 
 
+def source_hash() -> str:
+    """sha256 prefix over the contents of every source / header of the library and the compile flags: the identity of a BUILD RECIPE,
+    the same on every machine and in every checkout path (unlike the .so's own hash, which embeds path-derived symbol ids).  It is
+    compiled into the library (``mhmr_source_hash()``), so a shipped ``libmhmr.so`` says which sources it was made from."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES) + sorted(HEADERS):
+        with open(os.path.normpath(os.path.join(CSRC, name)), "rb") as f:
+            h.update(os.path.basename(name).encode() + b"\0" + f.read() + b"\0")
+    h.update(repr((COMMON_FLAGS, sorted(EXTRA_FLAGS.items()))).encode())
+    return h.hexdigest()[:16]
+
+
+def built_source_hash(path: str | None = None) -> str | None:
+    """The source hash compiled into an existing libmhmr.so (None: no library, or one from before the hash existed).  Read from the
+    file's bytes (capi.hip plants the marker string), NOT through dlopen: a library loaded here would be the one the process keeps
+    even after build() has replaced the file."""
+    import re
+    path = path or LIB_PATH
+    if not os.path.isfile(path):
+        return None
+    with open(path, "rb") as f:
+        m = re.search(rb"MHMR_SOURCE_HASH=([0-9a-f]{16})", f.read())
+    return m.group(1).decode() if m else None
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP translation unit for gfx950 (hipcc cross-compiles without a GPU; one object per source, in parallel) and link
-    csrc/libmhmr.so."""
+    csrc/libmhmr.so.  An existing library is kept only if the source hash compiled into it equals the hash of the sources beside it
+    (file times say nothing about a library that travelled from another machine)."""
     from concurrent.futures import ThreadPoolExecutor
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS] + [os.path.abspath(__file__)]
-    if not force and os.path.isfile(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    want = source_hash()
+    if not force and built_source_hash() == want:
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + COMMON_FLAGS
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f'-DMHMR_SOURCE_HASH="{want}"'] + COMMON_FLAGS
 
     def compile_one(name):
         obj = os.path.join(objdir, name.replace(".hip", ".o"))
@@ -92,7 +118,7 @@ class HphDesc(C.Structure):
                                    "nearness")] + [("fn", _f)] +
                 [(n, _vp) for n in ("off1_w", "off1_b", "off2_w", "off2_b", "cq_x", "cq_y", "cv_x", "cv_y", "init_tail",
                                     "tok_w", "tok_b")] + [("layers", C.POINTER(HphLayer))] +
-                [(n, _vp) for n in ("dec_w", "dec_b", "zc", "token", "x", "xn", "t1", "t2", "kv", "dec", "det_row")])
+                [(n, _vp) for n in ("dec_w", "dec_b", "zc", "token", "x", "xn", "t1", "t2", "kv", "dec", "det_row", "nvalid")])
 
 
 class LbsConsts(C.Structure):
@@ -102,6 +128,7 @@ class LbsConsts(C.Structure):
 
 _SIGS = {
     "mhmr_version": ([], _i),
+    "mhmr_source_hash": ([], C.c_char_p),
     "mhmr_vit_forward": ([C.POINTER(VitDesc), _vp, _vp, _vp, _i, _vp], _i),
     "mhmr_gemm16": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mhmr_gemm16_ex": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -115,6 +142,8 @@ _SIGS = {
     "mhmr_detect_scores": ([_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "mhmr_detect_count": ([_vp, _i, _i, _i, _f, _vp, _vp], _i),
     "mhmr_detect_write": ([_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "mhmr_detect_write_cap": ([_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),
+    "mhmr_person_groups": ([_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp], _i),
     "mhmr_camera_embed": ([_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp], _i),
     "mhmr_hph_forward": ([C.POINTER(HphDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i,
                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),

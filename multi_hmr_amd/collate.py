@@ -150,8 +150,11 @@ def allgather_persons_async(batched: dict, capacity: int, image_offset: int = 0,
 def persons_from_batched(batched: dict, fields=None) -> list:
     """[P, ...] tensors -> the reference's list of per-person dicts (model.py:329-347)."""
     fields = fields_of(batched) if fields is None else fields
-    P = batched[fields[0][0]].shape[0]
-    return [{k: batched[k][i] for k, _ in fields} for i in range(P)]
+    keys = [k for k, _ in fields]
+    if batched[keys[0]].shape[0] == 0:
+        return []
+    # one unbind per key instead of P x len(keys) indexing calls
+    return [dict(zip(keys, vals)) for vals in zip(*(batched[k].unbind(0) for k in keys))]
 
 
 def batched_from_persons(persons: list, fields, device) -> dict:

@@ -659,6 +659,7 @@ int launch_attn64(const void* qk, const void* vt, void* out, int B, int T, int T
         hipLaunchKernelGGL((attn64_kernel<MHMR_DT_F16, RING>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags);
     else
         hipLaunchKernelGGL((attn64_kernel<MHMR_DT_BF16, RING>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags);
+    MHMR_CHECK_LAUNCH();
     return 0;
 }
 
@@ -673,6 +674,7 @@ int launch_attn(const void* qk, const void* vt, void* out, int B, int T, int Tp,
         hipLaunchKernelGGL((attn_kernel<MHMR_DT_F16, NW, RING, MODE>), dim3(grid), dim3(64 * NW), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags);
     else
         hipLaunchKernelGGL((attn_kernel<MHMR_DT_BF16, NW, RING, MODE>), dim3(grid), dim3(64 * NW), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags);
+    MHMR_CHECK_LAUNCH();
     return 0;
 }
 
@@ -696,28 +698,28 @@ int mhmr_launch_attention_ex(const void* qk, const void* vt, void* out, int B, i
     if (variant == 0 && flags == nullptr) return MHMR_ERR_BAD_ARG;
     const float limit = exp2f(limit_log2);
     prof_begin(PROF_ATTN, s);
+    int rc = 0;
     switch (variant) {
         case 0: {
-            launch_attn<4, 2, 3>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
-            launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);      // returns at once where flags[wg] == 0
+            rc = launch_attn<4, 2, 3>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
+            if (!rc) rc = launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);      // returns at once where flags[wg] == 0
             break;
         }
-        case 1: launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, nullptr, s); break;
-        case 2: launch_attn<4, 2, 2>(qk, vt, out, B, T, Tp, C, H, dtype, limit, nullptr, s); break;
-        case 3: launch_attn<8, 3, 2>(qk, vt, out, B, T, Tp, C, H, dtype, limit, nullptr, s); break;
+        case 1: rc = launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, nullptr, s); break;
+        case 2: rc = launch_attn<4, 2, 2>(qk, vt, out, B, T, Tp, C, H, dtype, limit, nullptr, s); break;
+        case 3: rc = launch_attn<8, 3, 2>(qk, vt, out, B, T, Tp, C, H, dtype, limit, nullptr, s); break;
         case 4:
         case 5: {     // 64 queries per wave (attn64_kernel) + the gated textbook fallback; 4: 3-slot K/V ring, 5: 2-slot ring
             if (flags == nullptr) return MHMR_ERR_BAD_ARG;
-            if (variant == 4) launch_attn64<3>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
-            else launch_attn64<2>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
-            launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
+            rc = variant == 4 ? launch_attn64<3>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s)
+                              : launch_attn64<2>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
+            if (!rc) rc = launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
             break;
         }
         default: return MHMR_ERR_BAD_ARG;
     }
     prof_end(PROF_ATTN, s, 4.0 * B * H * (double)T * T * 64);
-    MHMR_CHECK_LAUNCH();
-    return 0;
+    return rc;
 }
 
 int mhmr_launch_attention(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, int* flags,

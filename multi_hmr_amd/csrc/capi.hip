@@ -18,9 +18,10 @@ int mhmr_launch_linear_f32(const float* X, int ldx, const int* row_idx, const fl
 int mhmr_launch_layernorm_f32(const float* in, const float* w, const float* b, float* out, int rows, int C, float eps, hipStream_t s);
 int mhmr_launch_scores(const void* hid, int ld, const float* w2, const float* b2, float* scores, int rows, int C, int dtype, hipStream_t s);
 int mhmr_launch_detect_count(const float* scores, int B, int G, int nms_kernel, float thr, int* counts, hipStream_t s);
-int mhmr_launch_detect_write(const float* scores, int B, int G, int nms_kernel, float thr, const int* base, int* det_b, int* det_y, int* det_x, float* det_score, hipStream_t s);
+int mhmr_launch_detect_write(const float* scores, int B, int G, int nms_kernel, float thr, const int* base, int* det_b, int* det_y, int* det_x, float* det_score, int cap, hipStream_t s);
+int mhmr_launch_person_groups(const int* counts, const int* det_b, int P, int B, int cap, int* base, int* gstart, int ngcap, int* chunks, int nccap, int* info, hipStream_t s);
 int mhmr_launch_camera_embed(const float* Kmat, const float* freq, int B, int G, int patch, float* zK, void* ctx16, int Kc, int C, int dtype, hipStream_t s);
-int mhmr_launch_hph_inputs(const float* feat32, const float* zK, const int* det_b, const int* det_y, const int* det_x, const float* cq_x, const float* cq_y, const float* cv_x, const float* cv_y, const float* init_tail, int ntail, float* zc, float* token, int Ktok, void* ctx16, int Kc, int* det_row, int P, int G, int C, int dtype, hipStream_t s);
+int mhmr_launch_hph_inputs(const float* feat32, const float* zK, const int* det_b, const int* det_y, const int* det_x, const float* cq_x, const float* cq_y, const float* cv_x, const float* cv_y, const float* init_tail, int ntail, float* zc, float* token, int Ktok, void* ctx16, int Kc, int* det_row, int P, int G, int C, int dtype, const int* nvalid, hipStream_t s);
 int mhmr_launch_hph_self_attn(const float* qkv, const int* gstart, float* out, int ngroups, int nmax, int heads, hipStream_t s);
 int mhmr_launch_hph_cross_attn(const float* q, const float* kv, const int* chunks, int nchunks, float* out, int heads, int N, hipStream_t s);
 int mhmr_launch_hph_decode(const float* dec, int ldd, int nb, const float* Kmat, const int* det_b, float fn, int nearness, float* rotmat, float* rotvec, float* betas, float* expr, float* dist_pp, float* dist, int P, hipStream_t s);
@@ -75,6 +76,13 @@ void prof_end(int kind, hipStream_t s, double work) {
 extern "C" {
 
 int mhmr_version(void) { return MHMR_VERSION; }
+
+#ifndef MHMR_SOURCE_HASH
+#define MHMR_SOURCE_HASH "unknown"
+#endif
+// (the marker prefix lets _lib.built_source_hash() find the value in the file without loading it)
+static const char g_source_hash[] = "MHMR_SOURCE_HASH=" MHMR_SOURCE_HASH;
+const char* mhmr_source_hash(void) { return g_source_hash + 17; }
 
 int mhmr_prof_enable(int kind) {
     if (kind >= PROF_KINDS) return MHMR_ERR_BAD_ARG;
@@ -198,6 +206,10 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
     for (int l = 0; l < d->L; ++l) {
         const mhmr_vit_block& k = d->blocks[l];
         if (!fold && k.flags) return MHMR_ERR_BAD_ARG;               // folded weights cannot run through the plain LayerNorm path
+        // block 0's norm1 follows the patch embedding, whose epilogue leaves no row statistics: it cannot be folded (include/mhmr.h);
+        // a folded linear needs its column sums
+        if (l == 0 && (k.flags & 1)) return MHMR_ERR_BAD_ARG;
+        if (((k.flags & 1) && !k.qkv_colsum) || ((k.flags & 2) && !k.fc1_colsum)) return MHMR_ERR_BAD_ARG;
         const bool f1 = fold && (k.flags & 1), f2 = fold && (k.flags & 2);
         // the V and output projections may carry the low halves of their weights ([W_hi | W_lo] along k, one accumulator chain)
         const void* v_w = k.v_w2 ? k.v_w2 : (const void*)((const char*)k.qkv_w + (size_t)2 * C * C * esz);
@@ -280,7 +292,16 @@ int mhmr_detect_count(const float* scores, int B, int G, int nms_kernel, float t
 int mhmr_detect_write(const float* scores, int B, int G, int nms_kernel, float thr, const int* base, int* det_b, int* det_y,
                       int* det_x, float* det_score, void* stream) {
     if (nms_kernel < 1 || B <= 0) return MHMR_ERR_BAD_ARG;
-    return mhmr_launch_detect_write(scores, B, G, nms_kernel, thr, base, det_b, det_y, det_x, det_score, (hipStream_t)stream);
+    return mhmr_launch_detect_write(scores, B, G, nms_kernel, thr, base, det_b, det_y, det_x, det_score, 0x7fffffff, (hipStream_t)stream);
+}
+int mhmr_detect_write_cap(const float* scores, int B, int G, int nms_kernel, float thr, const int* base, int* det_b, int* det_y,
+                          int* det_x, float* det_score, int cap, void* stream) {
+    if (nms_kernel < 1 || B <= 0 || cap < 0) return MHMR_ERR_BAD_ARG;
+    return mhmr_launch_detect_write(scores, B, G, nms_kernel, thr, base, det_b, det_y, det_x, det_score, cap, (hipStream_t)stream);
+}
+int mhmr_person_groups(const int* counts, const int* det_b, int P, int B, int cap, int* base, int* gstart, int ngroups_cap, int* chunks,
+                       int nchunks_cap, int* info, void* stream) {
+    return mhmr_launch_person_groups(counts, det_b, P, B, cap, base, gstart, ngroups_cap, chunks, nchunks_cap, info, (hipStream_t)stream);
 }
 int mhmr_camera_embed(const float* K, const float* freq, int B, int G, int patch, float* zK, void* ctx16, int ldctx, int C,
                       int dtype, void* stream) {
@@ -344,7 +365,7 @@ int mhmr_hph_forward(const mhmr_hph_desc* d, const float* feat32, const float* z
 
     // queries, mlp_offset input, context rows of the detected cells  (model.py:255-265, 500-517, 541-552)
     TRY(mhmr_launch_hph_inputs(feat32, zK, det_b, det_y, det_x, d->cq_x, d->cq_y, d->cv_x, d->cv_y, d->init_tail,
-                               318 + d->nb + 3, d->zc, d->token, d->Ktok, ctx16, d->Kc, d->det_row, P, d->G, C, d->dtype, s));
+                               318 + d->nb + 3, d->zc, d->token, d->Ktok, ctx16, d->Kc, d->det_row, P, d->G, C, d->dtype, d->nvalid, s));
     // mlp_offset (model.py:258) and loc (272-275)
     TRY(mhmr_launch_linear_f32(d->zc, C, nullptr, d->off1_w, C, d->off1_b, nullptr, 0, d->t1, C, P, C, C, MHMR_ACT_RELU, s));
     TRY(mhmr_launch_linear_f32(d->t1, C, nullptr, d->off2_w, C, d->off2_b, nullptr, 0, offset, 2, P, 2, C, MHMR_ACT_NONE, s));

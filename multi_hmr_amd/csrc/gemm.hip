@@ -14,6 +14,8 @@
 // so every lane owns 4 consecutive tokens of one channel.
 #include <stdlib.h>
 #include "mhmr_common.h"
+#include <string.h>
+#include <stdlib.h>
 #include "mhmr_internal.h"
 
 namespace {
@@ -215,11 +217,15 @@ int launch_dt(const GemmArgs& g, hipStream_t s) {
     const size_t lds = 4 * TILE_BYTES;
 #define MHMR_GEMM_CASE(E)                                                                                   \
     case E: {                                                                                               \
-        static bool attr_set = false;                                                                       \
-        if (!attr_set) {                                                                                    \
-            (void)hipFuncSetAttribute((const void*)gemm_kernel<DT, E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)lds);                                                            \
-            attr_set = true;                                                                                \
+        static DeviceOnce once;                                                                             \
+        int dev = 0;                                                                                        \
+        const int need = once.need(&dev);                                                                   \
+        if (need == -2) return MHMR_ERR_BAD_ARG;                                                            \
+        if (need >= 0) {                                                                                    \
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<DT, E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                               (int)lds);                                                   \
+            if (e != hipSuccess) return (int)e;                                                             \
+            once.mark(dev);                                                                                 \
         }                                                                                                   \
         hipLaunchKernelGGL((gemm_kernel<DT, E>), dim3(grid), dim3(256), lds, s, g);                         \
         break;                                                                                              \
@@ -245,6 +251,34 @@ int launch_dt(const GemmArgs& g, hipStream_t s) {
 
 bool mhmr_gemm256_eligible(const GemmArgs& g);
 int mhmr_launch_gemm256(const GemmArgs& g, int dtype, hipStream_t s);
+
+int mhmr_cu_count() {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (dev >= 0 && dev < 64) {
+        const int c = cus[dev].load(std::memory_order_relaxed);
+        if (c > 0) return c;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    if (dev >= 0 && dev < 64) cus[dev].store(prop.multiProcessorCount, std::memory_order_relaxed);
+    return prop.multiProcessorCount;
+}
+
+namespace {
+// log2(panels per column group) for the two wide output widths; default four panels (2) for both
+struct ColGroupEnv {
+    int narrow = 2, wide = 2;
+    static int lg(int v) { return v <= 0 ? 0 : v == 1 ? 2 : v == 2 ? 1 : v == 4 ? 2 : v == 8 ? 3 : v == 16 ? 4 : v == 32 ? 5 : 0; }
+    ColGroupEnv() {
+        const char* e = getenv("MHMR_COLGROUP");
+        if (!e) return;
+        narrow = wide = lg(atoi(e));
+        if (const char* c = strchr(e, ',')) wide = lg(atoi(c + 1));
+    }
+};
+}  // namespace
 // MHMR_GEMM128=1 forces the 128x128 kernel everywhere (A/B measurements, bisecting)
 static const bool g_force_gemm128 = getenv("MHMR_GEMM128") != nullptr;
 
@@ -276,8 +310,10 @@ int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s) {
         const int pct = st ? atoi(st) : (g.img_rows > 0 ? 0 : 100);
         if (g.epi == EPI_RESID && (g.M / 256) * (g.N / 256) >= 1024 && pct > 0)      // only when every CU walks several tiles
             g2.stagger_ticks = (int)((g.K / 64 * 1.4 + 18.0) * 25.0 * pct / 100.0);
-        static const char* cg = getenv("MHMR_COLGROUP");
-        g2.colgroup = cg ? atoi(cg) : 1;
+        // column-group order (gemm256.hip): MHMR_COLGROUP = "a[,b]" panels per group for N = 2048 (QK) [, N >= 4096 (fc1)]; 0 = off, 1 = 4
+        static const ColGroupEnv cge;
+        const int nbn = g.N / 256;
+        g2.colgroup = nbn >= 16 ? cge.wide : cge.narrow;
         // image of a row tile = umulhi(tm, magic), exact while tm * tiles_per_image < 2^32; one tile per image: magic 0 = identity
         if (g.img_rows > 256) g2.img_magic = (unsigned)((1ull << 32) / (unsigned)(g.img_rows >> 8)) + 1u;
         rc = mhmr_launch_gemm256(g2, dtype, s);

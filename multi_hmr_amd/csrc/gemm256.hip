@@ -93,8 +93,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     // Column-group order (wide outputs: QK N = 2048, fc1 N = 4096): an XCD keeps the SAME four weight column panels in every round
     // (2 MB of W stay in its L2 for the whole launch) and walks 8 row tiles of them per round, instead of 2 row tiles x all 16
     // column panels (every XCD re-fetched the whole 8 MB of fc1's W each round: 2.5 GB per launch for 0.28 GB of operands).
-    const int ncg = nbn >> 2;                                         // column groups of 4 panels
-    const bool colgroup = g.colgroup && G == 256 && (nbn & 3) == 0 && ncg > 1 && ncg <= 8 && (8 % ncg) == 0;
+    // g.colgroup = log2 of the panels per group (2: four panels x 8 row tiles per XCD and round, 3: eight panels x 4 row tiles)
+    const int cgl = g.colgroup, ncg = cgl > 0 ? nbn >> cgl : 0;      // column groups
+    const bool colgroup = cgl >= 1 && cgl <= 5 && G == 256 && (nbn & ((1 << cgl) - 1)) == 0 && ncg > 1 && ncg <= 8 && (8 % ncg) == 0;
 
     // ---- DMA source addressing: one half-tile = 2 passes of 64 rows; lane-linear LDS image, swizzle on the source ----
     const int srow = tid >> 3;                                  // 0..63
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         if (r >= full) return full * G + b;
         if (colgroup) {
             const int x = b & 7, slot = b >> 3;                       // XCD (speed only), slot 0..31 inside it
-            const int row = r * (G / nbn) + (x / ncg) * 8 + (slot >> 2), col = (x % ncg) * 4 + (slot & 3);
+            const int row = r * (G / nbn) + (x / ncg) * (32 >> cgl) + (slot >> cgl), col = ((x % ncg) << cgl) + (slot & ((1 << cgl) - 1));
             return row * nbn + col;
         }
         return first + r * G;
@@ -509,21 +510,21 @@ namespace {
 template <int DT>
 int launch256_dt(const GemmArgs& g, hipStream_t s) {
     const int ntiles = (g.M / 256) * (g.N / 256);
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MHMR_ERR_BAD_ARG;
-        ncu = prop.multiProcessorCount;
-    }
+    const int ncu = mhmr_cu_count();                   // of the CURRENT device
+    if (ncu <= 0) return MHMR_ERR_BAD_ARG;
     const int grid = ntiles < ncu ? ntiles : ncu;      // one persistent block per CU
+    // 160 KiB of dynamic LDS: the attribute is per device (DeviceOnce, mhmr_internal.h)
 #define MHMR_GEMM_LAUNCH(E, F)                                                                                 \
     {                                                                                                          \
-        static bool attr_set = false;                                                                          \
-        if (!attr_set) {                                                                                       \
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<DT, E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      LDS_BYTES);                                                              \
-            attr_set = true;                                                                                   \
+        static DeviceOnce once;                                                                                \
+        int dev = 0;                                                                                           \
+        const int need = once.need(&dev);                                                                      \
+        if (need == -2) return MHMR_ERR_BAD_ARG;                                                               \
+        if (need >= 0) {                                                                                       \
+            hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DT, E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                               LDS_BYTES);                                                     \
+            if (e != hipSuccess) return (int)e;                                                                \
+            once.mark(dev);                                                                                    \
         }                                                                                                      \
         hipLaunchKernelGGL((gemm256_kernel<DT, E, F>), dim3(grid), dim3(512), LDS_BYTES, s, g);                \
     }

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void detect_count_kernel(const float* __restri
 __global__ __launch_bounds__(256) void detect_write_kernel(const float* __restrict__ scores, int G, int k, int pad, float thr,
                                                            const int* __restrict__ base, int* __restrict__ det_b,
                                                            int* __restrict__ det_y, int* __restrict__ det_x,
-                                                           float* __restrict__ det_score) {
+                                                           float* __restrict__ det_score, int cap) {
     __shared__ int cnt[256];
     const int b = blockIdx.x, N = G * G, t = threadIdx.x;
     const float* heat = scores + (size_t)b * N;
@@ -217,9 +217,59 @@ __global__ __launch_bounds__(256) void detect_write_kernel(const float* __restri
     for (int n = n_lo; n < n_hi; ++n) {
         const float s = nms_score(heat, G, n / G, n % G, k, pad);
         if (s >= thr) {
-            det_b[off] = b; det_y[off] = n / G; det_x[off] = n % G; det_score[off] = s;
+            if (off < cap) { det_b[off] = b; det_y[off] = n / G; det_x[off] = n % G; det_score[off] = s; }      // (fixed-capacity callers)
             ++off;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Device-side bookkeeping of the person set: what the reference derives on the HOST from torch.where / the caller's idx
+// (model.py:146-151; rebatch / pad_to_max, utils/tensor_manip.py:7-45) -- per-image person counts, their exclusive prefix sums, the
+// ragged query groups of the decoder's self-attention and the <= 8-query work items of its cross-attention -- without a host round trip.
+//   counts != null (inference): per-image counts from detect_count_kernel;  counts == null (training hook): histogram of det_b[0..P)
+//   (persons sorted by image, as torch.where leaves them).  Persons beyond `cap` are dropped (the host notices total > cap and re-runs).
+//   base[b]            exclusive prefix sum of the counts (detect_write_kernel's write offsets)            [B]     (nullable)
+//   gstart[0..ngcap]   person offsets of the non-empty images; entries past the last group repeat the end (empty groups)
+//   chunks[3 * nccap]  (image, first person, count <= 8); entries past the last chunk are (0, 0, 0): their workgroups return
+//   info[4]            {persons kept = min(total, cap), groups, chunks, total}
+// One workgroup; the serial part is O(B + P / 8) on one lane (B = 32, P = 256: a few microseconds, off the critical path's host).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void person_groups_kernel(const int* __restrict__ counts, const int* __restrict__ det_b, int P, int B,
+                                                            int cap, int* __restrict__ base, int* __restrict__ gstart, int ngcap,
+                                                            int* __restrict__ chunks, int nccap, int* __restrict__ info) {
+    extern __shared__ int cnt[];      // [B]
+    const int t = threadIdx.x;
+    for (int b = t; b < B; b += 256) cnt[b] = counts ? counts[b] : 0;
+    __syncthreads();
+    if (!counts) {
+        for (int p = t; p < P; p += 256) {
+            const int b = det_b[p];
+            if (b >= 0 && b < B) atomicAdd(&cnt[b], 1);
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        int start = 0, total = 0, ng = 0, nc = 0;
+        gstart[0] = 0;
+        for (int b = 0; b < B; ++b) {
+            const int c = cnt[b];
+            if (base) base[b] = total;
+            total += c;
+            const int kept = min(c, max(cap - start, 0));
+            if (kept > 0) {
+                for (int q0 = 0; q0 < kept; q0 += 8) {
+                    if (nc < nccap) { chunks[3 * nc] = b; chunks[3 * nc + 1] = start + q0; chunks[3 * nc + 2] = min(8, kept - q0); }
+                    ++nc;
+                }
+                start += kept;
+                if (ng < ngcap) gstart[ng + 1] = start;
+                ++ng;
+            }
+        }
+        for (int g = min(ng, ngcap); g < ngcap; ++g) gstart[g + 1] = start;
+        for (int c = min(nc, nccap); c < nccap; ++c) { chunks[3 * c] = 0; chunks[3 * c + 1] = 0; chunks[3 * c + 2] = 0; }
+        info[0] = start; info[1] = min(ng, ngcap); info[2] = min(nc, nccap); info[3] = total;
     }
 }
 
@@ -288,9 +338,12 @@ __global__ __launch_bounds__(256) void hph_inputs_kernel(const float* __restrict
                                                          const float* __restrict__ cv_y, const float* __restrict__ init_tail,
                                                          int ntail, float* __restrict__ zc, float* __restrict__ token, int Ktok,
                                                          void* __restrict__ ctx16_, int Kc, int* __restrict__ det_row, int G,
-                                                         int C) {
+                                                         int C, const int* __restrict__ nvalid) {
     typedef typename Op<DT>::T T;
     const int p = blockIdx.x, Cc = C + 99;
+    // fixed-capacity callers: rows >= *nvalid are padding (detection (0, 0, 0)); they are computed like persons and sliced off by the
+    // host, but must not touch the context row of a cell nobody detected
+    const bool real = nvalid == nullptr || p < *nvalid;
     const int b = det_b[p], y = det_y[p], x = det_x[p];
     const size_t row = (size_t)b * G * G + (size_t)y * G + x;
     if (threadIdx.x == 0) det_row[p] = (int)row;
@@ -301,7 +354,7 @@ __global__ __launch_bounds__(256) void hph_inputs_kernel(const float* __restrict
             const float f = c < C ? feat32[row * C + c] : zK[row * 99 + (c - C)];
             if (c < C) zc[(size_t)p * C + c] = f;
             tv = f + (cq_x[(size_t)y * Cc + c] + cq_y[(size_t)x * Cc + c]);
-            cp[c] = (T)(f + (cv_x[(size_t)y * Cc + c] + cv_y[(size_t)x * Cc + c]));
+            if (real) cp[c] = (T)(f + (cv_x[(size_t)y * Cc + c] + cv_y[(size_t)x * Cc + c]));
         } else if (c < Cc + ntail) {
             tv = init_tail[c - Cc];
         }
@@ -355,7 +408,7 @@ __global__ __launch_bounds__(64) void hph_self_attn_kernel(const float* __restri
 // wave are merged with 3 xor-shuffle rounds, the CA_WAVES wave results through LDS in wave order (deterministic).  The loop
 // is latency-bound (one 256-byte K|V row pair per lane-slice per trip): a single wave per (chunk, head) walked 512 trips at
 // N = 4096 (0.56 ms per layer); 8 waves walk 64 each.
-// chunks: (image b, first query, count) int triples built on the host from the per-image counts.
+// chunks: (image b, first query, count) int triples (person_groups_kernel, or the host); count 0 = padding of the work list.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int CA_WAVES = 8;
 __global__ __launch_bounds__(64 * CA_WAVES) void hph_cross_attn_kernel(const float* __restrict__ q, const float* __restrict__ kv,
@@ -363,6 +416,7 @@ __global__ __launch_bounds__(64 * CA_WAVES) void hph_cross_attn_kernel(const flo
                                                             int N, float scale) {
     const int ch = blockIdx.x, h = blockIdx.y;
     const int b = chunks[3 * ch], q0 = chunks[3 * ch + 1], nq = chunks[3 * ch + 2];
+    if (nq <= 0) return;          // (person_groups_kernel pads the work list up to the launch's upper bound; uniform per workgroup)
     __shared__ float part[CA_WAVES][8][34];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, qi = lane & 7, sl = lane >> 3;
     const bool active = qi < nq;
@@ -560,9 +614,19 @@ int mhmr_launch_detect_count(const float* scores, int B, int G, int nms_kernel, 
 }
 
 int mhmr_launch_detect_write(const float* scores, int B, int G, int nms_kernel, float thr, const int* base, int* det_b,
-                             int* det_y, int* det_x, float* det_score, hipStream_t s) {
+                             int* det_y, int* det_x, float* det_score, int cap, hipStream_t s) {
     hipLaunchKernelGGL(detect_write_kernel, dim3(B), dim3(256), 0, s, scores, G, nms_kernel, nms_pad(nms_kernel), thr, base,
-                       det_b, det_y, det_x, det_score);
+                       det_b, det_y, det_x, det_score, cap);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+int mhmr_launch_person_groups(const int* counts, const int* det_b, int P, int B, int cap, int* base, int* gstart, int ngcap, int* chunks,
+                              int nccap, int* info, hipStream_t s) {
+    if (B <= 0 || B > 8192 || P < 0 || cap < 0 || ngcap < 0 || nccap < 0 || !gstart || !info || (nccap > 0 && !chunks)) return MHMR_ERR_BAD_ARG;
+    if (!counts && P > 0 && !det_b) return MHMR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(person_groups_kernel, dim3(1), dim3(256), (size_t)B * sizeof(int), s, counts, det_b, P, B, cap, base, gstart, ngcap,
+                       chunks, nccap, info);
     MHMR_CHECK_LAUNCH();
     return 0;
 }
@@ -581,14 +645,14 @@ int mhmr_launch_camera_embed(const float* Kmat, const float* freq, int B, int G,
 int mhmr_launch_hph_inputs(const float* feat32, const float* zK, const int* det_b, const int* det_y, const int* det_x,
                            const float* cq_x, const float* cq_y, const float* cv_x, const float* cv_y, const float* init_tail,
                            int ntail, float* zc, float* token, int Ktok, void* ctx16, int Kc, int* det_row, int P, int G, int C,
-                           int dtype, hipStream_t s) {
+                           int dtype, const int* nvalid, hipStream_t s) {
     if (P <= 0) return 0;
     if (dtype == MHMR_DT_F16)
         hipLaunchKernelGGL((hph_inputs_kernel<MHMR_DT_F16>), dim3(P), dim3(256), 0, s, feat32, zK, det_b, det_y, det_x, cq_x, cq_y,
-                           cv_x, cv_y, init_tail, ntail, zc, token, Ktok, ctx16, Kc, det_row, G, C);
+                           cv_x, cv_y, init_tail, ntail, zc, token, Ktok, ctx16, Kc, det_row, G, C, nvalid);
     else
         hipLaunchKernelGGL((hph_inputs_kernel<MHMR_DT_BF16>), dim3(P), dim3(256), 0, s, feat32, zK, det_b, det_y, det_x, cq_x, cq_y,
-                           cv_x, cv_y, init_tail, ntail, zc, token, Ktok, ctx16, Kc, det_row, G, C);
+                           cv_x, cv_y, init_tail, ntail, zc, token, Ktok, ctx16, Kc, det_row, G, C, nvalid);
     MHMR_CHECK_LAUNCH();
     return 0;
 }

@@ -34,7 +34,7 @@ struct GemmArgs {
     // Low-half weight pass: W = [W_hi | W_lo] along k (ldw >= K, K = 2 * a_k): k tiles >= a_k / 64 re-read the activation's k tiles
     // from the start, so acc = A . W_hi^T + A . W_lo^T in one accumulator chain.  0 = off.
     int a_k = 0;
-    int colgroup = 0;        // gemm256: column-group tile order for wide outputs (set by mhmr_launch_gemm; MHMR_COLGROUP=0 disables)
+    int colgroup = 0;        // gemm256: column-group tile order for wide outputs: log2 of the weight column panels an XCD keeps (2 = four panels, 3 = eight; 0 = off); set by mhmr_launch_gemm, MHMR_COLGROUP overrides
     // LayerNorm folded into the neighbouring GEMMs (gemm256 only): the LayerNorm pass of its own disappears.
     //   producer (EPI_RESID): besides the fp32 residual rows it writes x16 = their 16-bit copy (RAW, un-normalised: the next linear's A
     //   operand) and pstats[row][N / 64][2] = (sum, sum of squares) of every 64-column block of the row (summed over the row by
@@ -54,6 +54,25 @@ __host__ __device__ inline long long mhmr_phys_row(int m, int img_rows, int img_
 }
 
 int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s);
+
+// Per-DEVICE one-time kernel attributes (hipFuncAttributeMaxDynamicSharedMemorySize is a property of the function ON A DEVICE: a process
+// that drives a second GPU must set it there too).  One bit per device id in a launcher-local mask; setting an attribute twice from two
+// host threads is harmless, so a relaxed fetch_or is enough.  Device ids >= 64 set the attribute on every call.
+#include <atomic>
+struct DeviceOnce {
+    std::atomic<uint64_t> done{0};
+    // -> the current device id if the caller must (re)apply its attribute there, -1 if already applied, -2 on a HIP error
+    int need(int* dev_out) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return -2;
+        *dev_out = dev;
+        if (dev >= 0 && dev < 64 && ((done.load(std::memory_order_relaxed) >> dev) & 1ull)) return -1;
+        return dev;
+    }
+    void mark(int dev) { if (dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_relaxed); }
+};
+// multiProcessorCount of the CURRENT device (cached per device id)
+int mhmr_cu_count();
 
 // ---- per-kernel-family hipEvent profiling (bench.py roofline leg) ----
 enum ProfKind { PROF_GEMM = 0, PROF_ATTN = 1, PROF_LBS = 2, PROF_KINDS = 3 };

@@ -34,26 +34,33 @@ def forward_sharded(model, x, K, det_thresh=0.3, nms_kernel_size=3, group=None, 
     fields = person_fields(model) if fields is None else fields
     if device is None:
         device = next(model.parameters()).device if hasattr(model, "parameters") else x.device
-    persons, local_ids = [], torch.zeros(0, dtype=torch.int32, device=device)
+    # the local shard as BATCHED tensors [P_local, ...] (what the model has anyway: no person list -> torch.stack round trip)
+    batched = {k: torch.zeros(0, *shp, dtype=torch.float32, device=device) for k, shp in fields}
+    local_ids = torch.zeros(0, dtype=torch.int32, device=device)
     if len(imgs) > 0:
         xs, Ks = x[imgs.start:imgs.stop].to(device), K[imgs.start:imgs.stop].to(device)
-        persons, local_ids = _forward_with_image_ids(model, xs, Ks, det_thresh, nms_kernel_size)
-    batched = collate.batched_from_persons(persons, fields, device)
+        b, local_ids = _forward_batched(model, xs, Ks, det_thresh, nms_kernel_size, fields, device)
+        if b:
+            batched = b
     out, image_index = collate.allgather_persons(batched, image_offset=imgs.start, image_index=local_ids, group=group, fields=fields)
     humans = collate.persons_from_batched(out, fields)
     return (humans, image_index) if return_image_index else humans
 
 
-def _forward_with_image_ids(model, xs, Ks, det_thresh, nms_kernel_size):
-    """Inference on the local shard + the local image id of every person.  The reference's person dicts carry no image id (only their
-    order does): ``multi_hmr_amd.Model`` reports them (``return_image_index=True``); any other callable with the reference's signature
-    is run one image at a time."""
+def _forward_batched(model, xs, Ks, det_thresh, nms_kernel_size, fields, device):
+    """Inference on the local shard -> (dict of [P, ...] tensors or {} when nobody is detected, local image id [P] int32).  The
+    reference's person dicts carry no image id (only their order does): ``multi_hmr_amd.Model`` reports them together with the batched
+    tensors (``return_batched=True``); any other callable with the reference's signature is run one image at a time and its person
+    list is stacked."""
+    if getattr(model, "supports_batched", False):
+        batched, ids = model(xs, K=Ks, det_thresh=det_thresh, nms_kernel_size=nms_kernel_size, return_batched=True)
+        return batched, ids.to(torch.int32)
     if getattr(model, "supports_image_index", False):
         persons, ids = model(xs, K=Ks, det_thresh=det_thresh, nms_kernel_size=nms_kernel_size, return_image_index=True)
-        return persons, ids.to(torch.int32)
+        return (collate.batched_from_persons(persons, fields, device) if persons else {}), ids.to(torch.int32)
     ids, persons = [], []
     for b in range(xs.shape[0]):
         pb = model(xs[b:b + 1], K=Ks[b:b + 1], det_thresh=det_thresh, nms_kernel_size=nms_kernel_size)
         persons += pb
         ids += [b] * len(pb)
-    return persons, torch.tensor(ids, dtype=torch.int32, device=xs.device)
+    return (collate.batched_from_persons(persons, fields, device) if persons else {}), torch.tensor(ids, dtype=torch.int32, device=xs.device)

@@ -272,7 +272,9 @@ class Model(nn.Module):
                                     num_betas=num_betas, mean_params=_load_mean_params(kwargs.get("mean_params")))
         self._packed = None                 # tensors + descriptors of the current (device, precision, parameters)
         self._ws = vit.WorkspaceCache()     # the workspaces of the most recent batch sizes
-        self._idx_counts = None             # (identity of the last training-hook idx[0], its per-image counts on the host)
+        self._person_cap = {}               # batch size -> person-row capacity of the next inference forward (fixed-capacity heads)
+        self._streams = None                # side streams + events of the split backbone (_run_backbone)
+        self.split = kwargs.get("split")    # image blocks of the backbone on streams of their own (None: MHMR_SPLIT, default 2)
         for p in self.parameters():
             p.requires_grad_(False)
 
@@ -355,20 +357,68 @@ class Model(nn.Module):
         self._packed = P
         return P
 
+    def _nsplit(self, B):
+        """Image blocks of the batch that run the backbone on streams of their own (MHMR_SPLIT / ``split=``; default 2 for even
+        batches of >= 8 images).  Images never interact inside the backbone, so the blocks are independent launches sequences: the
+        persistent GEMM / attention launches of one block start on the CUs that the tail of the other block's launch leaves idle
+        (launch ramps and tails are ~3 % of a single-stream forward).  Results do not depend on it (every kernel
+        is batch-invariant: tests/test_gpu_fullsize.py)."""
+        n = self.split if self.split is not None else int(os.environ.get("MHMR_SPLIT", "0"))
+        if n <= 0:
+            n = 2 if (B >= 8 and B % 2 == 0) else 1
+        while n > 1 and (B % n or B // n < 1):
+            n -= 1
+        return n
+
     def _workspace(self, P, B):
         def extra(P, B, z):
             Mp = roundup(B * P["N"], 128)
             return dict(ctx16=z(Mp, P["Kc"]), zK=z(B * P["N"], 99, dtype=torch.float32), scores=z(B * P["N"], dtype=torch.float32),
-                        counts=z(B, dtype=torch.int32), kv=z(Mp, P["hph"]["n_kv"], dtype=torch.float32))
-        return self._ws.get(P, B, extra)
+                        counts=z(B, dtype=torch.int32), kv=z(Mp, P["hph"]["n_kv"], dtype=torch.float32),
+                        hid_cls=z(Mp, P["C"]))
+        return self._ws.get(P, B, extra, self._nsplit(B))
 
     # -------------------------------------------------------------------------------------------------- forward
+    def _side_streams(self, dev, n):
+        """n - 1 side streams (+ one fork and n - 1 join events) of this model on `dev`, created once."""
+        key = (dev.index, n)
+        if self._streams is None or self._streams[0] != key:
+            self._streams = (key, [torch.cuda.Stream(device=dev) for _ in range(n - 1)], torch.cuda.Event(),
+                             [torch.cuda.Event() for _ in range(n - 1)])
+        return self._streams[1:]
+
+    def _run_backbone(self, P, ws, x):
+        """mhmr_vit_forward over the image blocks of the workspace: block 0 on the caller's stream, the others on side streams that
+        fork from it and join it again (so the caller's stream semantics hold: everything enqueued before is visible to every block,
+        everything enqueued after sees every block's output)."""
+        L = _lib.lib()
+        dev, parts, Kc, N, Cd = x.device, ws["parts"], P["Kc"], P["N"], P["C"]
+        main = torch.cuda.current_stream(dev)
+        esz_ctx = ws["ctx16"].element_size()
+        img_elems = x.shape[1] * x.shape[2] * x.shape[3]
+
+        def launch(part, stream):
+            i0 = part["img0"]
+            _lib.check(L.mhmr_vit_forward(C.byref(part["desc"]), x.data_ptr() + i0 * img_elems * 4, ws["feat32"].data_ptr() + i0 * N * Cd * 4,
+                                          ws["ctx16"].data_ptr() + i0 * N * Kc * esz_ctx, Kc, stream.cuda_stream), "mhmr_vit_forward")
+
+        if len(parts) == 1:
+            launch(parts[0], main)
+            return
+        streams, fork, joins = self._side_streams(dev, len(parts))
+        fork.record(main)
+        for part, st, ev in zip(parts[1:], streams, joins):
+            st.wait_event(fork)
+            launch(part, st)
+            ev.record(st)
+        launch(parts[0], main)
+        for ev in joins:
+            main.wait_event(ev)
+
     def backbone_features(self, x):
         """[B,3,S,S] -> [B,N,C] fp32 patch features (reference blocks/dinov2.py:16-26), as a view of the workspace."""
         P, ws, stream = self._prepare(x)
-        L = _lib.lib()
-        _lib.check(L.mhmr_vit_forward(C.byref(ws["vit_desc"]), x.data_ptr(), ws["feat32"].data_ptr(), ws["ctx16"].data_ptr(),
-                                      P["Kc"], stream), "mhmr_vit_forward")
+        self._run_backbone(P, ws, x)
         return ws["feat32"].view(x.shape[0], P["N"], P["C"])
 
     def _prepare(self, x):
@@ -389,94 +439,114 @@ class Model(nn.Module):
     def forward(self, x, idx=None, det_thresh=0.3, nms_kernel_size=3, K=None, is_training=False, *args, **kwargs):
         """Same contract as the reference ``Model.forward`` (model.py:205-349): inference -> list of per-person dicts
         (empty list if nobody is detected); ``is_training=True`` (needs ``idx``) -> dict of batched tensors.
-        Extension used by ``distributed.forward_sharded``: ``return_image_index=True`` (inference only) -> (persons, image id [P])."""
+        Extension used by ``distributed.forward_sharded``: ``return_image_index=True`` (inference only) -> (persons, image id [P]);
+        ``return_batched=True`` (inference only) -> (dict of batched tensors [P, ...], image id [P]) instead of the per-person list."""
         with torch.autocast("cuda", enabled=False):     # demo.forward_model wraps us in fp16 autocast (demo.py:117)
             return self._forward(x.float().contiguous(), idx, det_thresh, nms_kernel_size, K, is_training,
-                                 bool(kwargs.get("return_image_index", False)))
+                                 bool(kwargs.get("return_image_index", False)), bool(kwargs.get("return_batched", False)))
 
     supports_image_index = True
+    supports_batched = True
+    #: keys of a person dict, in the reference's order (model.py:330-346)
+    PERSON_KEYS = ("scores", "loc", "transl", "transl_pelvis", "rotvec", "expression", "shape", "v3d", "j3d", "j2d")
 
-    def _forward(self, x, idx, det_thresh, nms_kernel_size, K, is_training, with_ids=False):
+    def _forward(self, x, idx, det_thresh, nms_kernel_size, K, is_training, with_ids=False, batched=False):
         L = _lib.lib()
         P, ws, stream = self._prepare(x)
         dev, B, G, N, Cdim, Kc = x.device, x.shape[0], P["G"], P["N"], P["C"], P["Kc"]
-        if is_training:
-            # the per-image person counts are needed on the HOST (ragged query groups below).  Taken BEFORE the first launch -- a
-            # device-resident idx read back after the backbone was enqueued would stall the host until the backbone has finished, with
-            # the head kernels not yet in the queue -- and remembered for an idx tensor that is handed in again unchanged.
-            assert idx is not None
-            i0 = idx[0]
-            key = (i0.data_ptr(), i0._version, tuple(i0.shape), str(i0.device), B)
-            if self._idx_counts is None or self._idx_counts[0] != key:
-                self._idx_counts = (key, torch.bincount(i0.detach().cpu().long(), minlength=B))
-            counts_pinned = self._idx_counts[1]
         dt = P["dt_id"]
         K = K.to(device=dev, dtype=torch.float32).contiguous()
         assert K.shape == (B, 3, 3)
         Mp = ws["ctx16"].shape[0]
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
 
         # 1. backbone (model.py:229) -> feat32 + 16-bit context operand
-        _lib.check(L.mhmr_vit_forward(C.byref(ws["vit_desc"]), x.data_ptr(), ws["feat32"].data_ptr(), ws["ctx16"].data_ptr(), Kc, stream),
-                   "mhmr_vit_forward")
+        self._run_backbone(P, ws, x)
         # 2. camera embedding (model.py:262) -> zK + context operand columns C..C+98
         _lib.check(L.mhmr_camera_embed(K.data_ptr(), P["freq"].data_ptr(), B, G, PATCH, ws["zK"].data_ptr(), ws["ctx16"].data_ptr(), Kc,
                                        Cdim, dt, stream), "mhmr_camera_embed")
         # 3. detection scores (model.py:135): mlp_classif.0 + ReLU on MFMA, then the C->1 read-out + clamped sigmoid
         _lib.check(L.mhmr_gemm16(ws["ctx16"].data_ptr(), Kc, P["cls0_w"].data_ptr(), Cdim, Mp, Cdim, Cdim, P["cls0_b"].data_ptr(), None,
-                                 ws["hid"].data_ptr(), Cdim, None, 0, 128, 1, Mp, _lib.EPI_OP16_RELU, dt, stream), "mhmr_gemm16(classif)")
-        _lib.check(L.mhmr_detect_scores(ws["hid"].data_ptr(), Cdim, P["cls2_w"].data_ptr(), P["cls2_b"].data_ptr(), ws["scores"].data_ptr(),
+                                 ws["hid_cls"].data_ptr(), Cdim, None, 0, 128, 1, Mp, _lib.EPI_OP16_RELU, dt, stream), "mhmr_gemm16(classif)")
+        _lib.check(L.mhmr_detect_scores(ws["hid_cls"].data_ptr(), Cdim, P["cls2_w"].data_ptr(), P["cls2_b"].data_ptr(), ws["scores"].data_ptr(),
                                         B * N, Cdim, dt, stream), "mhmr_detect_scores")
         scores = ws["scores"].view(B, G, G, 1)
 
-        # 4. NMS + threshold + ordered compaction (model.py:141-149), or the caller's idx (training hook, :150-151)
-        if not is_training:
-            thr = float(det_thresh[0] if isinstance(det_thresh, list) else det_thresh)
-            k = int(nms_kernel_size)
-            _lib.check(L.mhmr_detect_count(ws["scores"].data_ptr(), B, G, k, thr, ws["counts"].data_ptr(), stream), "mhmr_detect_count")
-            counts = ws["counts"].cpu()                       # the one host sync (the reference syncs in torch.where)
-            Pn = int(counts.sum())
-            if Pn == 0:
-                return ([], torch.zeros(0, dtype=torch.int32, device=dev)) if with_ids else []
-            base = (torch.cumsum(counts, 0) - counts).to(torch.int32).to(dev)
-            det = torch.empty(3, Pn, dtype=torch.int32, device=dev)
-            scores_det = torch.empty(Pn, dtype=torch.float32, device=dev)
-            _lib.check(L.mhmr_detect_write(ws["scores"].data_ptr(), B, G, k, thr, base.data_ptr(), det[0].data_ptr(), det[1].data_ptr(),
-                                           det[2].data_ptr(), scores_det.data_ptr(), stream), "mhmr_detect_write")
-            idx = (det[0].long(), det[1].long(), det[2].long(), torch.zeros(Pn, dtype=torch.long, device=dev))
-        else:
+        # 4. the person set.  Its bookkeeping -- per-image counts, write offsets, the ragged query groups of the decoder (rebatch /
+        # pad_to_max semantics, utils/tensor_manip.py:7-45, without the padding) -- is made ON THE DEVICE (mhmr_person_groups): the
+        # training hook needs no host round trip at all, inference reads the person count back AFTER the whole forward is enqueued.
+        def tables(cap):
+            ngc, ncc = min(B, cap), cap // 8 + min(B, cap)
+            return i32(ngc + 1), i32(3 * max(ncc, 1)), i32(4), ngc, ncc
+
+        if is_training:
+            # the caller's idx (training hook, model.py:150-151); persons sorted by image as torch.where leaves them
+            assert idx is not None
             idx = tuple(i.to(dev) for i in idx)
             Pn = int(idx[0].shape[0])
+            out = {"scores": scores.clone()}
+            if Pn == 0:
+                return out
             det = torch.stack([idx[0], idx[1], idx[2]]).to(torch.int32).contiguous()
-            counts = counts_pinned
-            scores_det = None
-        out = {"scores": scores.clone() if is_training else scores}
-        if Pn == 0:
+            gstart_t, chunks_t, info, ngc, ncc = tables(Pn)
+            _lib.check(L.mhmr_person_groups(None, det[0].data_ptr(), Pn, B, Pn, None, gstart_t.data_ptr(), ngc, chunks_t.data_ptr(), ncc,
+                                            info.data_ptr(), stream), "mhmr_person_groups")
+            out.update(self._heads(P, ws, K, det, Pn, gstart_t, ngc, chunks_t, ncc, None, stream))
             return out
 
-        # 5. ragged query groups (rebatch / pad_to_max semantics, utils/tensor_manip.py:7-45, without the padding)
-        groups = self._idx_counts[2] if (is_training and len(self._idx_counts) > 2) else None
-        if groups is None:
-            cl = [int(c) for c in counts.tolist()]
-            gstart, chunks, start = [0], [], 0
-            for b, c in enumerate(cl):
-                if c == 0:
-                    continue
-                for q0 in range(0, c, 8):
-                    chunks += [b, start + q0, min(8, c - q0)]
-                start += c
-                gstart.append(start)
-            meta = torch.tensor(gstart + chunks, dtype=torch.int32).to(dev)
-            groups = (meta[: len(gstart)], meta[len(gstart):], len(gstart) - 1, len(chunks) // 3, max(cl))
-            if is_training:
-                self._idx_counts = self._idx_counts[:2] + (groups,)
-        gstart_t, chunks_t, ngroups, nchunks, nmax = groups
+        # NMS + threshold + ordered compaction (model.py:141-149)
+        thr = float(det_thresh[0] if isinstance(det_thresh, list) else det_thresh)
+        k = int(nms_kernel_size)
+        _lib.check(L.mhmr_detect_count(ws["scores"].data_ptr(), B, G, k, thr, ws["counts"].data_ptr(), stream), "mhmr_detect_count")
 
-        # 6. HPH (model.py:258-283, 287-298)
+        def detect_and_heads(cap):
+            det, scores_det, base = i32(3, cap), torch.zeros(cap, dtype=torch.float32, device=dev), i32(B)
+            gstart_t, chunks_t, info, ngc, ncc = tables(cap)
+            _lib.check(L.mhmr_person_groups(ws["counts"].data_ptr(), None, 0, B, cap, base.data_ptr(), gstart_t.data_ptr(), ngc,
+                                            chunks_t.data_ptr(), ncc, info.data_ptr(), stream), "mhmr_person_groups")
+            _lib.check(L.mhmr_detect_write_cap(ws["scores"].data_ptr(), B, G, k, thr, base.data_ptr(), det[0].data_ptr(), det[1].data_ptr(),
+                                               det[2].data_ptr(), scores_det.data_ptr(), cap, stream), "mhmr_detect_write_cap")
+            o = self._heads(P, ws, K, det, cap, gstart_t, ngc, chunks_t, ncc, info, stream)
+            o["scores"] = scores_det
+            return o, det, info
+
+        # Fixed capacity: the heads are enqueued for `cap` person rows (a little above the previous batch's count; rows behind the real
+        # persons are padding that the kernels compute and nobody reads), and the ONE host synchronisation -- the person count, which the
+        # reference takes in torch.where in the MIDDLE of its forward (model.py:146) -- comes after the last launch, when it costs the GPU
+        # nothing.  The first call, and a batch with more persons than the capacity, take the count first (exact sizes).
+        cap = self._person_cap.get(B)
+        o = None
+        if cap is not None:
+            o, det, info = detect_and_heads(cap)
+            Pn = int(info[3].item())                       # the host sync
+            if Pn > cap:
+                o = None
+        else:
+            Pn = int(ws["counts"].sum().item())            # the host sync (first call)
+        self._person_cap[B] = roundup(max(Pn + Pn // 4 + 8, 32), 32)
+        if Pn == 0:
+            return (([] if not batched else {}), torch.zeros(0, dtype=torch.int32, device=dev)) if (with_ids or batched) else []
+        if o is None:
+            o, det, info = detect_and_heads(Pn)
+        # 8. per-person dicts (model.py:329-347); v2d / rotmat are computed but not exposed, as in the reference
+        cols = {n: o[n][:Pn] for n in self.PERSON_KEYS}
+        ids = det[0][:Pn]
+        if batched:
+            return cols, ids
+        # (one unbind per key instead of Pn x 10 indexing calls: 3 ms -> 1 ms of host time at 256 persons)
+        keys = tuple(cols)
+        persons = [dict(zip(keys, vals)) for vals in zip(*(t.unbind(0) for t in cols.values()))]
+        return (persons, ids) if with_ids else persons
+
+    def _heads(self, P, ws, K, det, Pn, gstart_t, ngc, chunks_t, ncc, info, stream):
+        """HPH (model.py:258-283, 287-298) + SMPL-X layer (model.py:319-321) for Pn person rows -> dict of batched tensors."""
+        L = _lib.lib()
+        dev, B, G, N, Cdim, Kc, dt = K.device, K.shape[0], P["G"], P["N"], P["C"], P["Kc"], P["dt_id"]
         h = P["hph"]
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         wsp = dict(zc=f(Pn, Cdim), token=f(Pn, h["Ktok"]), x=f(Pn, h["dim"]), xn=f(Pn, h["dim"]),
-                   t1=f(Pn, max(3 * h["inner"], h["mlp"], Cdim)), t2=f(Pn, h["inner"]), dec=f(Pn, h["Ndec"]),
-                   det_row=torch.empty(Pn, dtype=torch.int32, device=dev))
+                   t1=f(Pn, max(3 * h["inner"], h["mlp"], Cdim)), t2=torch.zeros(Pn, h["inner"], dtype=torch.float32, device=dev),
+                   dec=f(Pn, h["Ndec"]), det_row=torch.empty(Pn, dtype=torch.int32, device=dev))
         d = _lib.HphDesc()
         d.dtype, d.C, d.G, d.N, d.Kc = dt, Cdim, G, N, Kc
         d.dim, d.heads, d.mlp, d.depth, d.nb, d.Ktok, d.Ndec = h["dim"], h["heads"], h["mlp"], h["depth"], h["nb"], h["Ktok"], h["Ndec"]
@@ -488,17 +558,17 @@ class Model(nn.Module):
         for n, t in wsp.items():
             setattr(d, n, t.data_ptr())
         d.kv = ws["kv"].data_ptr()
+        d.nvalid = info.data_ptr() if info is not None else None
         offset, loc = f(Pn, 2), f(Pn, 2)
         rotmat, rotvec = f(Pn, 53, 3, 3), f(Pn, 53, 3)
         shape, expression = f(Pn, h["nb"]), f(Pn, 10)
         dist_pp, dist = f(Pn, 1), f(Pn, 1)
+        # ngc / Pn / ncc are upper bounds of the group count, the largest group and the work-item count (include/mhmr.h)
         _lib.check(L.mhmr_hph_forward(C.byref(d), ws["feat32"].data_ptr(), ws["zK"].data_ptr(), ws["ctx16"].data_ptr(), det[0].data_ptr(),
-                                      det[1].data_ptr(), det[2].data_ptr(), Pn, gstart_t.data_ptr(), ngroups, nmax,
-                                      chunks_t.data_ptr(), nchunks, K.data_ptr(), B, offset.data_ptr(), loc.data_ptr(),
+                                      det[1].data_ptr(), det[2].data_ptr(), Pn, gstart_t.data_ptr(), ngc, Pn,
+                                      chunks_t.data_ptr(), ncc, K.data_ptr(), B, offset.data_ptr(), loc.data_ptr(),
                                       rotmat.data_ptr(), rotvec.data_ptr(), shape.data_ptr(), expression.data_ptr(), dist_pp.data_ptr(),
                                       dist.data_ptr(), stream), "mhmr_hph_forward")
-
-        # 7. SMPL-X layer (model.py:319-321)
         lb = P["lbs"]
         V = lb["V"]
         v3d, v2d = f(Pn, V, 3), f(Pn, V, 2)
@@ -508,15 +578,6 @@ class Model(nn.Module):
                                       dist.data_ptr(), K.data_ptr(), det[0].data_ptr(), Pn, ws_F.data_ptr(), ws_A.data_ptr(),
                                       ws_xf.data_ptr(), v3d.data_ptr(), v2d.data_ptr(), j3d.data_ptr(), j2d.data_ptr(), transl.data_ptr(),
                                       stream), "mhmr_lbs_forward")
-        out.update({"offset": offset, "dist": dist, "dist_postprocessed": dist_pp, "expression": expression, "rotmat": rotmat,
-                    "shape": shape, "rotvec": rotvec, "loc": loc, "v3d": v3d, "j3d": j3d, "j2d": j2d, "v2d": v2d,
-                    "transl": transl, "transl_pelvis": j3d[:, [0]]})
-        if is_training:
-            return out
-        # 8. per-person dicts (model.py:329-347); v2d / rotmat are computed but not exposed, as in the reference
-        # (one unbind per key instead of Pn x 10 indexing calls: 3 ms -> 1 ms of host time at 256 persons)
-        cols = {"scores": scores_det, "loc": loc, "transl": transl, "transl_pelvis": out["transl_pelvis"], "rotvec": rotvec,
-                "expression": expression, "shape": shape, "v3d": v3d, "j3d": j3d, "j2d": j2d}
-        keys = tuple(cols)
-        persons = [dict(zip(keys, vals)) for vals in zip(*(t[:Pn].unbind(0) for t in cols.values()))]
-        return (persons, det[0]) if with_ids else persons
+        return {"offset": offset, "dist": dist, "dist_postprocessed": dist_pp, "expression": expression, "rotmat": rotmat,
+                "shape": shape, "rotvec": rotvec, "loc": loc, "v3d": v3d, "j3d": j3d, "j2d": j2d, "v2d": v2d,
+                "transl": transl, "transl_pelvis": j3d[:, [0]]}

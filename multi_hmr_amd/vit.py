@@ -163,38 +163,50 @@ class WorkspaceCache:
     def clear(self):
         self._ws = {}
 
-    def get(self, P: dict, B: int, extra):
-        """extra(P, B, z) -> dict of additional workspace tensors (z = zero-tensor factory in the operand dtype)."""
-        key = (id(P), B)
+    def get(self, P: dict, B: int, extra, nsplit: int = 1):
+        """extra(P, B, z) -> dict of additional workspace tensors (z = zero-tensor factory in the operand dtype).
+
+        nsplit > 1: the batch is cut into nsplit contiguous image blocks with a backbone workspace + descriptor each (``ws["parts"]``:
+        dicts with ``desc``, ``B``, ``img0``), so that the blocks can run on different streams (model.Model, MHMR_SPLIT); ``feat32`` and
+        the extras cover the whole batch.  The top-level buffer names (``hid`` ...) are those of part 0."""
+        key = (id(P), B, nsplit)
         if key in self._ws:
             self._ws[key] = self._ws.pop(key)             # most recent last
             return self._ws[key]
         while len(self._ws) >= self.KEEP:                 # free the oldest before allocating
             self._ws.pop(next(iter(self._ws)))
+        if B % nsplit:
+            raise ValueError(f"batch {B} does not split into {nsplit} equal image blocks")
         dev, tdt = P["device"], P["tdt"]
-        Cd, N, Tp, H = P["C"], P["N"], padded_tokens(P, B), P["H"]
-        Mp = roundup(B * N, 128)
+        Bh = B // nsplit
+        Cd, N, Tp, H = P["C"], P["N"], padded_tokens(P, Bh), P["H"]
         z = lambda *s, dtype=tdt: torch.zeros(*s, dtype=dtype, device=dev)
-        if P.get("fold") and not row_map(P, B):
-            raise _lib.MhmrError(f"batch {B} is too large for the token-row map this pack's folded LayerNorms need (32-bit residual offsets of "
+        if P.get("fold") and not row_map(P, Bh):
+            raise _lib.MhmrError(f"batch {Bh} is too large for the token-row map this pack's folded LayerNorms need (32-bit residual offsets of "
                                  "the 256x256 kernel); build the model with lnfold=False for such batches")
-        ws = dict(a_patch=z(Mp, P["Kp"]), resid=z(B * Tp, Cd, dtype=torch.float32), xn=z(B * Tp, Cd), qk=z(B * Tp, 2 * Cd),
-                  vt=z(B * H * 64, Tp), att=z(B * Tp, Cd), hid=z(B * Tp, 4 * Cd), feat32=z(B * N, Cd, dtype=torch.float32),
-                  attn_flags=z(_lib.lib().mhmr_attention_flag_count(B, Tp, H), dtype=torch.int32))
-        if P.get("fold"):
-            ws.update(pstats=z(B * Tp, Cd // 64, 2, dtype=torch.float32), rowstats=z(B * Tp, 2, dtype=torch.float32))
-        ws.update(extra(P, B, z))
         v = P["vit"]
-        d = _lib.VitDesc()
-        d.dtype, d.B, d.S, d.C, d.H, d.L = P["dt_id"], B, P["S"], Cd, H, P["L"]
-        d.G, d.N, d.T, d.Tp, d.Kp = P["G"], N, P["T"], Tp, P["Kp"]
-        d.patch_w, d.patch_b, d.cls_pos0, d.pos = v["patch_w"], v["patch_b"], v["cls_pos0"], v["pos"]
-        d.blocks = C.cast(v["blocks"], C.POINTER(_lib.VitBlock))
-        d.norm_w, d.norm_b = v["norm_w"], v["norm_b"]
-        for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid", "attn_flags"):
-            setattr(d, n, ws[n].data_ptr())
-        d.pstats = ws["pstats"].data_ptr() if P.get("fold") else None
-        d.rowstats = ws["rowstats"].data_ptr() if P.get("fold") else None
-        ws["vit_desc"], ws["Tp"] = d, Tp
+        parts = []
+        for i in range(nsplit):
+            Mp = roundup(Bh * N, 128)
+            b = dict(a_patch=z(Mp, P["Kp"]), resid=z(Bh * Tp, Cd, dtype=torch.float32), xn=z(Bh * Tp, Cd), qk=z(Bh * Tp, 2 * Cd),
+                     vt=z(Bh * H * 64, Tp), att=z(Bh * Tp, Cd), hid=z(Bh * Tp, 4 * Cd),
+                     attn_flags=z(_lib.lib().mhmr_attention_flag_count(Bh, Tp, H), dtype=torch.int32))
+            if P.get("fold"):
+                b.update(pstats=z(Bh * Tp, Cd // 64, 2, dtype=torch.float32), rowstats=z(Bh * Tp, 2, dtype=torch.float32))
+            d = _lib.VitDesc()
+            d.dtype, d.B, d.S, d.C, d.H, d.L = P["dt_id"], Bh, P["S"], Cd, H, P["L"]
+            d.G, d.N, d.T, d.Tp, d.Kp = P["G"], N, P["T"], Tp, P["Kp"]
+            d.patch_w, d.patch_b, d.cls_pos0, d.pos = v["patch_w"], v["patch_b"], v["cls_pos0"], v["pos"]
+            d.blocks = C.cast(v["blocks"], C.POINTER(_lib.VitBlock))
+            d.norm_w, d.norm_b = v["norm_w"], v["norm_b"]
+            for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid", "attn_flags"):
+                setattr(d, n, b[n].data_ptr())
+            d.pstats = b["pstats"].data_ptr() if P.get("fold") else None
+            d.rowstats = b["rowstats"].data_ptr() if P.get("fold") else None
+            parts.append(dict(desc=d, B=Bh, img0=i * Bh, bufs=b))
+        ws = dict(parts[0]["bufs"])
+        ws["feat32"] = z(B * N, Cd, dtype=torch.float32)
+        ws.update(extra(P, B, z))
+        ws["parts"], ws["vit_desc"], ws["Tp"] = parts, parts[0]["desc"], Tp
         self._ws[key] = ws
         return ws

@@ -16,14 +16,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_builds_loads_and_exports_every_declared_symbol():
     _lib.build()
     lib = _lib.lib()
-    assert lib.mhmr_version() == _lib.VERSION == 102
+    assert lib.mhmr_version() == _lib.VERSION == 103
     header = open(os.path.join(ROOT, "include", "mhmr.h")).read()
-    declared = set(re.findall(r"\bint\s+(mhmr_[a-z0-9_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(?:int|const char\*)\s+(mhmr_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for sym in declared:
         assert getattr(lib, sym) is not None
     # argument validation happens before any launch, so it is testable without a GPU
     assert lib.mhmr_prof_enable(99) == -1
+    # the library says which sources it was built from, and build() trusts that, not file times
+    assert lib.mhmr_source_hash().decode() == _lib.source_hash() == _lib.built_source_hash()
 
 
 def test_pos_embed_bicubic_matches_torch_scale_factor_form():
