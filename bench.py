@@ -66,10 +66,16 @@ def lib_sha16():
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
+def lib_source_hash():
+    """Hash of the sources + flags the LOADED library was built from (compiled into it; the same on every machine)."""
+    return _lib.lib().mhmr_source_hash().decode()
+
+
 def pmc_summary():
     """The newest committed rocprofv3 PMC summary (tools/pmc_traffic.py -> profiles/r*_pmc.json).  Counters cannot be read from
-    inside the timed process, so `traffic` comes from that file -- and only when it was measured on THIS build of libmhmr.so
-    (the summary records the library's sha256 prefix); otherwise traffic is null."""
+    inside the timed process, so `traffic` comes from that file -- and only when it was measured on a library built from THE SAME
+    SOURCES as the one running now (the summary records `mhmr_source_hash()`, which does not depend on the machine or the checkout
+    path; older summaries carry the .so's own sha256 prefix); otherwise traffic is null."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -79,7 +85,7 @@ def pmc_summary():
                     d = json.load(f)
             except (OSError, ValueError):
                 continue
-            if d.get("_lib_sha16") == lib_sha16():
+            if d.get("_source_hash") == lib_source_hash() or ("_source_hash" not in d and d.get("_lib_sha16") == lib_sha16()):
                 best = d
     return best
 
@@ -120,6 +126,25 @@ def time_steps(fn, steps, warmup, dev):
     return time.perf_counter() - t0
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` from a bare shell: start N ranks (one per GPU) of this same command under torch.distributed.run on a
+    free local port and hand its exit code back.  More ranks than GPUs -> ONE JSON error line, exit code 2."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if n > have:
+        print(json.dumps({"error": f"--gpus {n} requested, {have} GPU(s) visible on this node", "n_gpus": n, "gpus_visible": have,
+                          "metric": "images/sec (whole node)", "value": None}))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +162,8 @@ def main():
                          "averages are not mixed with the other configurations' shapes")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -145,7 +172,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        if rank == 0:
+            print(json.dumps({"error": f"--gpus {args.gpus} but WORLD_SIZE={world}", "n_gpus": args.gpus}))
+        sys.exit(2)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -157,11 +187,17 @@ def main():
 
     pending = []          # N > 1: the collation of step i travels over xGMI while step i + 1 computes (waited one step later)
     compute_ev = []       # N > 1: hipEvent pairs around the forward alone (separates compute from exposed collation)
+    # a real caller hands in a NEW idx tuple at every step: one set of tensor objects per step, made before the clock starts
+    # (the forward derives everything it needs from idx on the device, every step -- nothing is remembered between steps)
+    idx_steps = [tuple(t.clone() for t in idx) for _ in range(args.warmup + args.steps)]
+    step_no = [0]
 
     def step():
         if world > 1:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        idx = idx_steps[step_no[0] % len(idx_steps)]
+        step_no[0] += 1
         out = model(x, idx=idx, K=K, is_training=True)
         if world > 1:
             e1.record()
@@ -210,7 +246,8 @@ def main():
                                f"{q} pinned persons/image -> HPH (depth 2) -> SMPL-X LBS; image-sharded x{world}",
                    "global_batch": world * B, "parallelism": f"dp{world} (images)"},
         "mfma_utilisation_whole_forward": round((gemm_fl + attn_fl) * B * args.steps / dt / 1e12 / PEAK_MFMA_TFLOPS, 4),
-        "lib_sha16": lib_sha16(),
+        "lib_sha16": lib_sha16(), "source_hash": lib_source_hash(),
+        "backbone_image_blocks": model._nsplit(B),
     }
     if world > 1:
         result["multi_gpu"] = {"max_rank_compute_ms_per_step": round(compute_ms / args.steps, 3),
@@ -309,12 +346,14 @@ def inference_bench(model, x, K, out_train, B, q, dev, steps=20, warmup=3):
     keep = (m == s) & (s >= thr)
     idx = tuple(torch.where(keep)) + (torch.zeros(int(keep.sum()), dtype=torch.long, device=dev),)
     dt_hook = time_steps(lambda: model(x, idx=idx, K=K, is_training=True), steps, warmup, dev)
+    gemm_fl, attn_fl = flops_per_image(model.img_size, model.embed_dim, len(model.backbone.encoder.blocks))
     return {"value": round(B * steps / dt, 2), "unit": "images/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+            "mfma_utilisation_whole_forward": round((gemm_fl + attn_fl) * B * steps / dt / 1e12 / PEAK_MFMA_TFLOPS, 4),
             "persons_per_step": len(persons), "det_thresh": thr, "nms_kernel_size": 3,
             "training_hook_same_detections_ms_per_step": round(1e3 * dt_hook / steps, 3),
             "host_side_share_ms_per_step": round(1e3 * (dt - dt_hook) / steps, 3),
-            "note": "is_training=False: detection + one D2H count sync + per-person dict list; host_side_share = inference-mode step minus the "
-                    "training-hook step pinned to the same detections"}
+            "note": "is_training=False: detection, heads enqueued for a person-row capacity, ONE D2H person-count read after the last launch, "
+                    "per-person dict list; host_side_share = inference-mode step minus the training-hook step pinned to the same detections"}
 
 
 def lbs_bench(model, dev, P=160, iters=20):

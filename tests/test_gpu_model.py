@@ -216,3 +216,122 @@ def test_forward_sharded_without_a_process_group_is_the_plain_forward(smplx_data
     assert len(a) == len(b) == int(gold["num_humans"]) and img.tolist() == sorted(img.tolist())
     assert all(torch.equal(p["v3d"], q["v3d"]) and torch.equal(p["scores"], q["scores"]) for p, q in zip(a, b))
     assert distributed.person_fields(model)[-1] == ("v3d", (10475, 3))
+
+
+def test_person_groups_on_the_device_match_the_host_bookkeeping():
+    """mhmr_person_groups (csrc/hph.hip) against the reference's host-side bookkeeping (torch.where order, model.py:146-151; rebatch /
+    pad_to_max, utils/tensor_manip.py:7-45): counts, write offsets, self-attention groups, <= 8-query work items -- from the detection
+    counts and from a training-hook idx, with empty images, > 8 persons in one image, a capacity below the total, and launch bounds
+    above the real table sizes (the padding entries must be empty groups / count-0 items)."""
+    import ctypes as C
+    from multi_hmr_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    for counts, cap in (([3, 0, 11, 1, 0, 8, 9], 64), ([3, 0, 11, 1, 0, 8, 9], 20), ([0, 0, 0], 8), ([17], 17), ([1] * 40, 64)):
+        B, total = len(counts), sum(counts)
+        kept, left = [], cap
+        for c in counts:
+            kept.append(min(c, max(left, 0)))
+            left -= kept[-1]
+        gstart, chunks, start = [0], [], 0
+        for b, c in enumerate(kept):
+            if c == 0:
+                continue
+            for q0 in range(0, c, 8):
+                chunks += [b, start + q0, min(8, c - q0)]
+            start += c
+            gstart.append(start)
+        ngc, ncc = min(B, cap) + 2, cap // 8 + min(B, cap) + 3          # bounds above the sufficient ones
+        for from_counts in (True, False):
+            if not from_counts and cap < total:
+                continue                                                    # (the hook's capacity is its person count)
+            cnt = torch.tensor(counts, dtype=torch.int32).cuda()
+            det_b = torch.tensor([b for b, c in enumerate(counts) for _ in range(c)], dtype=torch.int32).cuda()
+            base, gs, ch, info = (torch.full((n,), -7, dtype=torch.int32).cuda() for n in (B, ngc + 1, 3 * ncc, 4))
+            _lib.check(L.mhmr_person_groups(cnt.data_ptr() if from_counts else None, det_b.data_ptr() if total else None, total, B, cap,
+                                            base.data_ptr(), gs.data_ptr(), ngc, ch.data_ptr(), ncc, info.data_ptr(), st), "groups")
+            assert info.tolist() == [start, len(gstart) - 1, len(chunks) // 3, total], (counts, cap, from_counts, info.tolist())
+            assert base.tolist() == [sum(counts[:b]) for b in range(B)]
+            assert gs.tolist() == gstart + [start] * (ngc + 1 - len(gstart))
+            assert ch.tolist() == chunks + [0] * (3 * ncc - len(chunks))
+
+
+def test_training_hook_follows_every_new_idx(smplx_data, mean_params):
+    """Round-3 advisor finding: the hook used to remember per-image counts for an idx tensor it recognised by ADDRESS; a new idx of
+    the same shape that re-used a freed address was grouped with the old counts.  Nothing is remembered now (the groups are made on
+    the device from the idx handed in): forwards with different idx tensors of one shape -- allocated and freed so that addresses
+    recur -- each equal the forward of a fresh model on that idx."""
+    cfg = dict(backbone="dinov2_vits14", img_size=224, depth_override=2, batch=4, persons=[3, 1, 0, 4], seed=5)
+    sd = make_golden.case_state_dict(cfg)
+    x, K, idx = make_golden.case_inputs(cfg)
+    xc, Kc = x.cuda(), K.cuda()
+    model = build(cfg, smplx_data, mean_params, "f16", sd)
+    P = int(idx[0].shape[0])
+    variants = [[3, 1, 0, 4], [0, 4, 4, 0], [8, 0, 0, 0], [2, 2, 2, 2]]       # same person count, different images
+    for round_ in range(2):
+        for cnt in variants:
+            img = torch.tensor([b for b, c in enumerate(cnt) for _ in range(c)])
+            assert img.numel() == P
+            cur = (img, idx[1].clone(), idx[2].clone(), idx[3].clone())
+            ic = tuple(t.cuda() for t in cur)              # new device tensors every time; the previous ones were freed
+            got = model(xc, idx=ic, K=Kc, is_training=True)
+            ref = build(cfg, smplx_data, mean_params, "f16", sd)(xc, idx=tuple(t.cuda() for t in cur), K=Kc, is_training=True)
+            for k in ("v3d", "rotmat", "shape", "expression", "transl"):
+                assert torch.equal(got[k], ref[k]), (cnt, k)
+            del ic, got
+
+
+def test_fixed_capacity_inference_equals_the_exact_path(smplx_data, mean_params):
+    """Inference enqueues the heads for a person-row capacity and reads the person count back after the last launch.  First call
+    (no capacity known: count first), second call (capacity above the count: padding rows), a threshold that detects MORE persons than
+    the capacity (overflow -> re-run at the exact size), and one that detects nobody: always the persons of the exact path, bit for bit,
+    and the padding never touches the context rows of cells nobody detected."""
+    cfg = make_golden.CASES["vits_448_infer"]
+    gold = np.load(os.path.join(GOLD, "vits_448_infer.npz"))
+    sd = make_golden.case_state_dict(cfg)
+    sd["mlp_classif.2.bias"] = torch.from_numpy(gold["classif_bias"])
+    x, K, _ = make_golden.case_inputs(cfg)
+    xc, Kc = x.cuda(), K.cuda()
+    thr = float(gold["det_thresh"])
+
+    def exact(t):
+        m = build(cfg, smplx_data, mean_params, "f16", sd)         # a fresh model has no capacity: it takes the count first
+        return m(xc, K=Kc, det_thresh=t, nms_kernel_size=cfg["nms_kernel_size"])
+
+    model = build(cfg, smplx_data, mean_params, "f16", sd)
+    seq = [thr, thr, thr * 0.5, thr, 2.0, thr, thr * 0.25, thr * 0.25]
+    for i, t in enumerate(seq):
+        cap_before = dict(model._person_cap)
+        got, ids = model(xc, K=Kc, det_thresh=t, nms_kernel_size=cfg["nms_kernel_size"], return_image_index=True)
+        ref = exact(t)
+        assert len(got) == len(ref) == int(ids.numel()), (i, t, len(got), len(ref), cap_before)
+        for p, q in zip(got, ref):
+            for k in p:
+                assert torch.equal(p[k], q[k]), (i, t, k, cap_before)
+    assert len(exact(thr * 0.25)) > len(exact(thr)) > 0
+
+
+@pytest.mark.parametrize("name", ["vitl_224_train", "vits_224_train"])
+def test_backbone_image_blocks_on_side_streams_change_nothing(name, smplx_data, mean_params):
+    """Model(split=n): the backbone of n image blocks on streams of their own (fork / join around mhmr_vit_forward).  Every kernel is
+    batch-invariant, so the outputs are bit-equal to the single-stream run -- also when forwards follow each other without a
+    synchronisation in between (the next forward's side streams must wait for the previous forward's consumers of the workspaces)."""
+    cfg = dict(make_golden.CASES[name], batch=4)
+    cfg["persons"] = [2, 0, 3, 1]
+    sd = make_golden.case_state_dict(cfg)
+    x, K, idx = make_golden.case_inputs(cfg)
+    xc, Kc, ic = x.cuda(), K.cuda(), tuple(i.cuda() for i in idx)
+
+    def mk(split):
+        m = Model(backbone=cfg["backbone"], img_size=cfg["img_size"], smplx_data=smplx_data, mean_params=mean_params,
+                  backbone_depth=cfg["depth_override"], precision="f16", split=split)
+        m.load_state_dict(sd, strict=True)
+        return m.to("cuda:0").eval()
+    one = mk(1)(xc, idx=ic, K=Kc, is_training=True)
+    for split in (2, 4):
+        m = mk(split)
+        assert m._nsplit(4) == split
+        outs = [m(xc if i % 2 == 0 else xc.flip(0), idx=ic, K=Kc, is_training=True) for i in range(6)]       # back to back, no sync
+        for k in ("scores", "v3d", "rotmat", "shape", "expression", "transl", "j2d"):
+            assert torch.equal(outs[0][k], one[k]) and torch.equal(outs[4][k], one[k]), (split, k)
+        assert not torch.equal(outs[1]["v3d"], one["v3d"])

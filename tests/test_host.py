@@ -244,3 +244,19 @@ def test_extra_joint_tiles_of_the_packed_body_model(smplx_data):
     assert np.array_equal(xb[:21], np.tile([[1.0, 0.0, 0.0]], (21, 1))) and np.allclose(xb[21:], np.asarray(smplx_data["lmk_bary_coords"]))
     unused = [Vl + 48 * 4 + 16 * k + i for k in range(3) for i in range(8, 16)]           # slots 72..79 of the fifth tile
     assert all(not b16[v // 48][..., v % 48, :].any() for v in unused)
+
+
+def test_bench_starts_its_own_ranks_and_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE): the script launches N ranks itself; more ranks than visible GPUs ->
+    ONE JSON error line and a non-zero exit code (here: no GPU at all)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert "error" in d and d["n_gpus"] == 2 and d["gpus_visible"] == torch.cuda.device_count()

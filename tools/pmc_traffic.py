@@ -7,8 +7,9 @@ SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE) it adds per kernel: 
 SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), the effective shader clock = (GRBM_GUI_ACTIVE / 8) / duration,
 and the LDS bank-conflict share of LDS-active cycles.
 <dir>/lbs/ (optional) holds the same passes over tools/lbs_bench.py 160: the SMPL-X layer's kernels at P = 160 are taken from
-there (inside the forward the layer runs at other person counts).  The summary records the sha256 prefix of the libmhmr.so it
-was measured on (`_lib_sha16`); bench.py reports `traffic` from it only when that matches the library it is running.
+there (inside the forward the layer runs at other person counts).  The summary records the hash of the sources the measured
+libmhmr.so was built from (`_source_hash`, compiled into the library; plus `_lib_sha16`, the file's own sha256 prefix); bench.py reports
+`traffic` from it only when `_source_hash` matches the library it is running.
 usage: tools/pmc_traffic.py <dir with FETCH_SIZE_counter_collection.csv, WRITE_SIZE_counter_collection.csv> > profiles/rNN_pmc.json"""
 import collections, csv, glob, hashlib, json, os, re, sys
 d = sys.argv[1]
@@ -80,5 +81,9 @@ al = sorted(((v["launches"], v["launches"] * v["total_bytes_per_launch"]) for k,
 if al:
     res["_attention_bytes_per_call"] = round(sum(b for _, b in al) / al[0][0])
 with open(os.path.join(ROOT, "multi_hmr_amd", "csrc", "libmhmr.so"), "rb") as f:
-    res["_lib_sha16"] = hashlib.sha256(f.read()).hexdigest()[:16]
+    blob = f.read()
+res["_lib_sha16"] = hashlib.sha256(blob).hexdigest()[:16]
+# the hash of the SOURCES the measured library was built from (compiled into it): what bench.py matches, machine-independent
+m = re.search(rb"MHMR_SOURCE_HASH=([0-9a-f]{16})", blob)
+res["_source_hash"] = m.group(1).decode() if m else None
 print(json.dumps(res, indent=1))
