@@ -514,13 +514,24 @@ class Model(nn.Module):
         # persons are padding that the kernels compute and nobody reads), and the ONE host synchronisation -- the person count, which the
         # reference takes in torch.where in the MIDDLE of its forward (model.py:146) -- comes after the last launch, when it costs the GPU
         # nothing.  The first call, and a batch with more persons than the capacity, take the count first (exact sizes).
+        # per-person dicts (model.py:329-347); v2d / rotmat are computed but not exposed, as in the reference.  One unbind per key
+        # instead of rows x 10 indexing calls (3 ms -> 1 ms of host time at 256 persons) -- and in the fixed-capacity path the dicts of
+        # ALL capacity rows are made BEFORE the count is read back, i.e. while the GPU is still busy with this forward: after the
+        # synchronisation only a list slice is left (views of padding rows are dropped unread).
+        keys = self.PERSON_KEYS
+
+        def person_dicts(o, rows):
+            return [dict(zip(keys, vals)) for vals in zip(*(o[n][:rows].unbind(0) for n in keys))]
+
         cap = self._person_cap.get(B)
-        o = None
+        o = persons = None
         if cap is not None:
             o, det, info = detect_and_heads(cap)
+            if not batched:
+                persons = person_dicts(o, cap)
             Pn = int(info[3].item())                       # the host sync
             if Pn > cap:
-                o = None
+                o = persons = None
         else:
             Pn = int(ws["counts"].sum().item())            # the host sync (first call)
         self._person_cap[B] = roundup(max(Pn + Pn // 4 + 8, 32), 32)
@@ -528,14 +539,10 @@ class Model(nn.Module):
             return (([] if not batched else {}), torch.zeros(0, dtype=torch.int32, device=dev)) if (with_ids or batched) else []
         if o is None:
             o, det, info = detect_and_heads(Pn)
-        # 8. per-person dicts (model.py:329-347); v2d / rotmat are computed but not exposed, as in the reference
-        cols = {n: o[n][:Pn] for n in self.PERSON_KEYS}
         ids = det[0][:Pn]
         if batched:
-            return cols, ids
-        # (one unbind per key instead of Pn x 10 indexing calls: 3 ms -> 1 ms of host time at 256 persons)
-        keys = tuple(cols)
-        persons = [dict(zip(keys, vals)) for vals in zip(*(t.unbind(0) for t in cols.values()))]
+            return {n: o[n][:Pn] for n in keys}, ids
+        persons = persons[:Pn] if persons is not None else person_dicts(o, Pn)
         return (persons, ids) if with_ids else persons
 
     def _heads(self, P, ws, K, det, Pn, gstart_t, ngc, chunks_t, ncc, info, stream):

