@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define MHMR_VERSION 103   /* 103: mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
+#define MHMR_VERSION 103   /* 103: mhmr_lbs_consts.basis16 layout (high halves for k < Kb - 64); mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
 
 #define MHMR_OK 0
 #define MHMR_ERR_BAD_ARG (-1)
@@ -283,8 +283,10 @@ typedef struct {
     int nb, Kinf;         /* num_betas, max skinning influences per vertex                                   */
     int center_joint;     /* JOINT_NAMES.index(person_center) = 15 ('head'); < 0 = person_center None: nothing is
                              recentred and the pelvis is added to the translation (smpl_layer.py:128-130)       */
-    const void* basis16;  /* f16 [Vp/48][Kb/8][2][3][48][8]: 1024 x [posedirs(486) | shapedirs(nb) | exprdirs(10)] as hi + lo,
-                             tile-major (the slice of a 48-vertex tile is one contiguous block)                   */
+    const void* basis16;  /* f16, 1024 x [posedirs(486) | shapedirs(nb) | exprdirs(10) | 0], tile-major (the slice of a 48-vertex tile is
+                             one contiguous block of 82944 values): [Vp/48]{ [Kb/8 - 8][3][48][8] the HIGH halves of k < Kb - 64 (pose
+                             correctives: one product per term in the kernel), then [8][2][3][48][8] hi + lo of the last 64 k (the last
+                             pose columns, every shape / expression direction: fp32 accuracy) }                              */
     const float* vtemp;   /* [3][Vp]           v_template, fp32                                                */
     const float* J0;      /* [55*3]            J_regressor . v_template                                      */
     const float* JS;      /* [55*3][nb+10]     J_regressor . [shapedirs | exprdirs]                          */

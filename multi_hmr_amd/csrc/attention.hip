@@ -88,6 +88,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
     }
     const int qt = bid % nqt, bh = bid / nqt;
     const int b = bh / H, h = bh - b * H;
+    constexpr int QB = 32 * NW;
+    // a workgroup whose query rows are ALL padding (rows per image padded to a multiple of 256: 1288^2 has 239 of them) has nothing to
+    // compute or store -- its output rows are never written by anyone and stay as allocated (zero); MODE 3 still owes its flags
+    if (qt * QB >= T) {
+        if constexpr (MODE == 3) {
+            if (lane == 0) flags[4 * bid + w] = 0;
+        }
+        return;
+    }
 
     const Tt* qk = (const Tt*)qk_;
     const Tt* vt = (const Tt*)vt_;
@@ -95,7 +104,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
     const size_t row0 = (size_t)b * Tp;
 
     // ---- Q fragments (B operand: lane (q = l31, hi) holds Q[q][16 ks + 8 hi + 0..7]) ----
-    constexpr int QB = 32 * NW;
     const int q_row = qt * QB + 32 * w + l31;
     const bool active = qt * QB + 32 * w < T;  // a wave whose 32 query rows are all padding (T = 64 n + 1: three of the four waves
                                                // of every image's last workgroup) skips the arithmetic and stores zeros

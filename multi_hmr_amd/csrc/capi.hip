@@ -200,7 +200,12 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
     auto rows = [&](GemmArgs& g) { g.img_rows = ir; g.img_stride = is; };
     // LayerNorm fold (GemmArgs in mhmr_internal.h): needs the token-row map (every block linear on the 256x256 kernel) and the two workspaces
     static const bool fold_env = !(getenv("MHMR_LNFOLD") && atoi(getenv("MHMR_LNFOLD")) == 0);
-    const bool fold = rowmap && fold_env && d->pstats && d->rowstats;
+    // ... or, without the row map (N not a multiple of 256: 1288^2, 518^2), every block linear on the 256x256 kernel over ALL B * Tp rows
+    // (Tp a multiple of 256: vit.padded_tokens): the class and padding rows are rows like any other, with block sums of their own
+    const bool allrows256 = !rowmap && rowmap_env && C % 256 == 0 && M % 256 == 0 && (uint64_t)M * (uint64_t)C * 4u < (1ull << 32);
+    const bool fold = (rowmap || allrows256) && fold_env && d->pstats && d->rowstats;
+    auto ln_stats = [&]() { return rowmap ? mhmr_launch_ln_stats(d->pstats, d->resid, d->rowstats, B, N, Tp, C, 1e-6f, s)
+                                          : mhmr_launch_ln_stats(d->pstats, d->resid, d->rowstats, 1, M, M, C, 1e-6f, s); };
     const long long rowC = (long long)Tp * C;
     const float* cls_stats = fold ? d->rowstats + (size_t)cls_row * 2 : nullptr;      // (mean, rstd) of image b's class row: + b * 2 Tp
     for (int l = 0; l < d->L; ++l) {
@@ -217,7 +222,7 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
         const void* p_w = k.proj_w2 ? k.proj_w2 : k.proj_w;
         const int p_k = k.proj_w2 ? 2 * C : C, p_ak = k.proj_w2 ? C : 0;
         // x = x + ls1 * proj(MHSA(norm1(x)))
-        if (f1) TRY(mhmr_launch_ln_stats(d->pstats, d->resid, d->rowstats, B, N, Tp, C, 1e-6f, s));
+        if (f1) TRY(ln_stats());
         else TRY(mhmr_launch_layernorm(d->resid, k.ln1_w, k.ln1_b, d->xn, M, C, 1e-6f, dt, s));
         {
             GemmArgs g{d->xn, C, k.qkv_w, C, Mg, 2 * C, C, k.qkv_b, nullptr, d->qk, 2 * C, nullptr, 0, Tp, d->H, Mg, EPI_OP16_QK};
@@ -257,7 +262,7 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
                                                 fold ? (char*)d->xn + (size_t)cls_row * C * esz : nullptr, rowC, s));
         }
         // x = x + ls2 * fc2(gelu(fc1(norm2(x))))
-        if (f2) TRY(mhmr_launch_ln_stats(d->pstats, d->resid, d->rowstats, B, N, Tp, C, 1e-6f, s));
+        if (f2) TRY(ln_stats());
         else TRY(mhmr_launch_layernorm(d->resid, k.ln2_w, k.ln2_b, d->xn, M, C, 1e-6f, dt, s));
         {
             GemmArgs g{d->xn, C, k.fc1_w, C, Mg, 4 * C, C, k.fc1_b, nullptr, d->hid, 4 * C, nullptr, 0, Tp, d->H, Mg, EPI_OP16_GELU};

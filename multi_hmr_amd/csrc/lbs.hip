@@ -10,10 +10,11 @@
 //     (fragment-major: one 1 KiB block per (person group, part, k step), see the kernel)
 //  2. lbs_vertex_kernel (the HBM-bound one; algorithmic bytes = blend basis 64.5 MB + skin weights 2.7 MB once, 214 KB per person out)
 //     One workgroup = one 48-vertex tile for ALL persons of the launch: the tile's slice of the blend basis D = [posedirs ; shapedirs ;
-//     exprdirs] (x 2^10, f16 hi + lo, 288 KiB) streams through an LDS ring exactly once -- HBM sees every basis byte once per launch --
-//     and compute wave g works on person group g (16 persons).  Both contractions run on the 16-bit matrix pipe at fp32 accuracy
-//     (x . y = xh.yh + xl.yh + xh.yl, fp32 accumulate; the dropped xl.yl term is 2^-22 relative):
-//       v_posed = v_template + F . D                      16 k-steps x 3 vertex blocks x 3 axes x 3 products   (B operand from LDS)
+//     exprdirs] (x 2^10, f16, 162 KiB) streams through an LDS ring exactly once -- HBM sees every basis byte once per launch --
+//     and compute wave g works on person group g (16 persons).  Both contractions run on the 16-bit matrix pipe; the skinning GEMM
+//     and the shape / expression part of the blend at fp32 accuracy (f16 pairs, x . y = xh.yh + xl.yh + xh.yl, fp32 accumulate; the
+//     dropped xl.yl term is 2^-22 relative), the millimetre-sized pose correctives with one product (LBS_EBYTES_HI below):
+//       v_posed = v_template + F . D                      16 k-steps x 3 vertex blocks x 3 axes x (1 | 3) products   (B operand from LDS)
 //       T       = sum_j w[v][j] [R | t]_j  (12 numbers)    2 k-steps x 12 components x 3 blocks x 3 products: the skinning blend as a
 //                 GEMM over the DENSE 64 x V weight matrix -- no per-vertex index list, no gathers of joint transforms
 //     Both land as (vertex = lane & 15, 4 persons per accumulator quad), so the rigid transform, the camera translation (added in
@@ -285,8 +286,8 @@ __device__ unsigned long long* g_lbs_stamps;
 #endif
 // grid = Vp / 48 workgroups (one 48-vertex tile = three 16-vertex MFMA column blocks, for ALL persons of the launch) of
 // LBS_NC compute waves + LBS_NL loader waves; at most one workgroup per CU (126 KB of LDS).
-//   * loader waves do nothing but move the tile's slice of the blend basis (288 KiB) through a 3-slot LDS ring of k eighths
-//     (36 KiB each) with global_load_lds: two eighths are always in flight, so HBM never waits for a barrier; their vmcnt stream
+//   * loader waves do nothing but move the tile's slice of the blend basis (162 KiB) through a 3-slot LDS ring of k eighths
+//     (18 KiB each, 36 KiB the last one) with global_load_lds: two eighths are always in flight, so HBM never waits for a barrier; their vmcnt stream
 //     holds only these copies, so the landing wait is an exact count.  They also bring the persons' [R0 | translation | K]
 //     records into LDS once.
 //   * compute wave w owns person group g0 + w (16 persons).  Its A operands (F16, A16: L2-resident, the same for every tile) are
@@ -295,7 +296,7 @@ __device__ unsigned long long* g_lbs_stamps;
 //     form, 48.6 us at 160 persons) each fragment fed 9 MFMAs and the vector-memory path (64 B/clk per CU) moved 57 B/clk in the
 //     blend and 2.7x its peak in the skinning products -- tools/lbs_timeline.py showed 8 us per group for 1.9 us of MFMAs no
 //     matter how far ahead the loads were issued.  The B operands come from LDS one block ahead.
-// Both contractions keep fp32 accuracy on the 16-bit matrix pipe (x . y = xh.yh + xl.yh + xh.yl).
+// The skinning GEMM and the last eighth of the blend keep fp32 accuracy on the 16-bit matrix pipe (x . y = xh.yh + xl.yh + xh.yl).
 struct __attribute__((packed, aligned(4))) Vec3 { float x, y, z; };
 struct __attribute__((packed, aligned(4))) Vec2 { float x, y; };
 constexpr int LBS_TV = 48, LBS_NST = LBS_TV / 16;      // vertices per tile, 16-vertex MFMA column blocks per tile
@@ -305,13 +306,21 @@ constexpr int LBS_NX = 72;                             // extra joints 55..126 (
 constexpr int LBS_NS = LBS_KB / 32;                    // k steps of 32
 constexpr int LBS_NE = 8, LBS_RING = 3;                // k eighths (2 steps each), LDS ring slots (4 slots: measured no faster at 1 / 20 / 160 persons)
 constexpr int LBS_ROW = LBS_TV * 8 * 2;                // bytes of one (k block, part, axis) row of the tile: 48 vertices x 8 k x f16
-constexpr int LBS_EBYTES = (LBS_KB / 8 / LBS_NE) * 6 * LBS_ROW;       // one eighth of the tile's slice: 36 KiB
-constexpr int LBS_EOPS = LBS_EBYTES / 1024 / LBS_NL;                  // 1-KiB copies per loader wave per eighth
+constexpr int LBS_EBYTES = (LBS_KB / 8 / LBS_NE) * 6 * LBS_ROW;       // one ring slot = one eighth of the tile's slice as an f16 PAIR: 36 KiB
+constexpr int LBS_EOPS = LBS_EBYTES / 1024 / LBS_NL;                  // 1-KiB copies per loader wave per eighth (pair form)
+// Precision of the blend (round 4): the first LBS_NE - 1 eighths (k < 448: pose correctives only, millimetres) carry the HIGH half of
+// the basis alone and are multiplied by the high half of the feature alone -- ONE product per term, |error| <= 2^-11 (|F| . |D|): a few
+// micrometres on a centimetre of pose corrective -- and the last eighth (k 448..511: the last pose columns and ALL shape / expression
+// directions, centimetres times |beta| up to 3) keeps the f16 pair and the three products (5e-7 m).  That is 180 instead of 432 blend
+// MFMAs per person group and tile, 162 instead of 288 KiB of basis per tile from HBM and LDS.
+constexpr int LBS_EBYTES_HI = LBS_EBYTES / 2;                         // an eighth with the high half only: 18 KiB
+constexpr int LBS_EOPS_HI = LBS_EOPS / 2;
+constexpr int LBS_TILE_BYTES = (LBS_NE - 1) * LBS_EBYTES_HI + LBS_EBYTES;   // basis bytes of one tile: 162 KiB
 constexpr int LBS_WBYTES = 8 * 2 * LBS_TV * 8 * 2;     // the tile's dense skin weights, hi + lo: 12 KiB
 constexpr int LBS_XREC = 24 * 4;                       // bytes of one person's record in ws_xf
 constexpr int LBS_LDS = LBS_RING * LBS_EBYTES + LBS_NC * 16 * LBS_XREC;
-static_assert(LBS_EBYTES % (1024 * LBS_NL) == 0 && LBS_EOPS == 18 && LBS_WBYTES / 1024 / LBS_NL == 6 && (LBS_RING == 3 || LBS_RING == 4),
-              "the landing waits below are written for 18 copies per wave and eighth, 6 for the weights, 1 or 2 eighths ahead");
+static_assert(LBS_EBYTES % (1024 * LBS_NL) == 0 && LBS_EOPS == 18 && LBS_EOPS_HI == 9 && LBS_WBYTES / 1024 / LBS_NL == 6 && LBS_RING == 3,
+              "the landing waits below are written for 9 / 18 copies per wave and eighth, 6 for the weights, one eighth ahead");
 static_assert(LBS_LDS <= 160 * 1024, "LDS");
 
 __device__ __forceinline__ void lbs_barrier() {
@@ -335,13 +344,16 @@ __device__ __forceinline__ void lbs_loader(const mhmr_lbs_consts& c, const float
             if (k * 1024 + lane * 16 < bytes) glds16(src + k * 1024, xrec + i * (16 * LBS_XREC) + k * 1024);
     }
     // tile-major basis: the tile's slice is one contiguous block, an eighth is 36 consecutive KiB; source and LDS image lane-linear
-    const _Float16* bsrc = (const _Float16*)c.basis16 + (size_t)blockIdx.x * (LBS_NE * LBS_EBYTES / 2) + lane * 8;
-    auto dma_e = [&](int e) {
+    const _Float16* bsrc = (const _Float16*)c.basis16 + (size_t)blockIdx.x * (LBS_TILE_BYTES / 2) + lane * 8;
+    auto dma_e = [&](int e) {          // (e is a compile-time value at every call: the loops around are unrolled)
         char* dst = smem + (e % LBS_RING) * LBS_EBYTES;
+        const int nops = e == LBS_NE - 1 ? LBS_EOPS : LBS_EOPS_HI;
 #pragma unroll
         for (int k = 0; k < LBS_EOPS; ++k) {
-            const int i = lw * LBS_EOPS + k;
-            glds16(bsrc + (size_t)e * (LBS_EBYTES / 2) + i * 512, dst + i * 1024);
+            if (k < nops) {
+                const int i = lw * nops + k;
+                glds16(bsrc + (size_t)e * (LBS_EBYTES_HI / 2) + i * 512, dst + i * 1024);
+            }
         }
     };
 #pragma unroll
@@ -352,10 +364,11 @@ __device__ __forceinline__ void lbs_loader(const mhmr_lbs_consts& c, const float
     for (int e = 0; e < LBS_NE; ++e) {
         // eighth e (and everything older: the records) has landed when at most the copies requested after it are outstanding:
         // the up to LBS_RING - 2 following eighths and, once requested, the weights
-        const int younger = LBS_EOPS * (min(LBS_NE - 1, e + LBS_RING - 2) - e) + (e > EW ? WOPS : 0);
-        if (younger == 36) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
-        else if (younger == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else if (younger == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        // (LBS_RING == 3: the one following eighth -- 9 copies, 18 for the last eighth -- ; the weights are requested at e == EW and
+        // published together with the last eighth by its vmcnt(0))
+        const int younger = e + 1 < LBS_NE ? (e + 1 == LBS_NE - 1 ? LBS_EOPS : LBS_EOPS_HI) : 0;
+        if (younger == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (younger == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lbs_barrier();                                   // ... and every compute wave is done with eighth e - 1: its slot is free
         if (e + LBS_RING - 1 < LBS_NE) dma_e(e + LBS_RING - 1);
@@ -384,10 +397,10 @@ __device__ __forceinline__ void lbs_compute(const mhmr_lbs_consts& c, const _Flo
 
     // A operands of k step sg (fragment-major: 1 KiB per (group, part, k step)), [set][hi | lo]
     H8 A[2][2];
-    auto load_a = [&](int set, int sg) {
+    auto load_a = [&](int set, int sg) {          // (the low half only where the pair form of the basis is: the last eighth's two steps)
         const _Float16* fh = F16 + ((((size_t)g * 2) * LBS_NS + sg) * 64 + lane) * 8;
         A[set][0] = *(const H8*)fh;
-        A[set][1] = *(const H8*)(fh + (size_t)LBS_NS * 512);
+        if (sg >= LBS_NS - 2) A[set][1] = *(const H8*)(fh + (size_t)LBS_NS * 512);
     };
     // skinning operands of component cmp: [set][xh t0, xh t1, xl t0, xl t1]
     H8 X[2][4];
@@ -413,12 +426,15 @@ __device__ __forceinline__ void lbs_compute(const mhmr_lbs_consts& c, const _Flo
     for (int e = 0; e < LBS_NE; ++e) {
         lbs_barrier();
         LBS_STAMP(1 + e);
-        const char* slot = smem + (e % LBS_RING) * LBS_EBYTES + g4 * (6 * LBS_ROW) + l15 * 16;     // + (4 s2) * 6 rows + (part * 3 + axis) rows + st * 256
+        const bool pair = e == LBS_NE - 1;                   // compile-time after unrolling
+        const int rows = pair ? 6 : 3;                       // (part, axis) rows per k block of this eighth
+        const char* slot = smem + (e % LBS_RING) * LBS_EBYTES + g4 * (rows * LBS_ROW) + l15 * 16;     // + (4 s2) * rows + (part * 3 + axis) rows + st * 256
         H8 B[2][6];
-        auto read_b = [&](int set, int j) {           // j = 3 * s2 + st: the six (part, axis) fragments of one vertex block of one k step
-            const char* b = slot + (j / 3) * (24 * LBS_ROW) + (j % 3) * 256;
+        auto read_b = [&](int set, int j) {           // j = 3 * s2 + st: the (part, axis) fragments of one vertex block of one k step
+            const char* b = slot + (j / 3) * (4 * rows * LBS_ROW) + (j % 3) * 256;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) B[set][k] = *(const H8*)(b + k * LBS_ROW);
+            for (int k = 0; k < 6; ++k)
+                if (k < rows) B[set][k] = *(const H8*)(b + k * LBS_ROW);
         };
         read_b(0, 0);
 #pragma unroll
@@ -434,7 +450,8 @@ __device__ __forceinline__ void lbs_compute(const mhmr_lbs_consts& c, const _Flo
             for (int prod = 0; prod < 3; ++prod)
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
-                    acc[st][a] = Op<MHMR_DT_F16>::mfma16(A[sg & 1][prod == 1 ? 1 : 0], B[j & 1][prod == 2 ? 3 + a : a], acc[st][a]);
+                    if (prod == 0 || pair)
+                        acc[st][a] = Op<MHMR_DT_F16>::mfma16(A[sg & 1][prod == 1 ? 1 : 0], B[j & 1][prod == 2 ? 3 + a : a], acc[st][a]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }

@@ -202,7 +202,9 @@ int mhmr_launch_layernorm(const float* in, const float* w, const float* b, void*
 int mhmr_launch_ln_stats(const float* pstats, const float* resid, float* rowstats, int B, int N, int Tp, int C, float eps, hipStream_t s) {
     if (C % 128 || C > 1024) return MHMR_ERR_BAD_SHAPE;       // nblk = C / 64 even, <= 16 (eight lanes x two blocks)
     const int patch_blocks = (B * N + 31) / 32;
-    hipLaunchKernelGGL(ln_stats_kernel, dim3(patch_blocks + (B + 3) / 4), dim3(256), 0, s, pstats, resid, rowstats, B, N, Tp, C, C / 64, eps,
+    // N == Tp: every row of an image has block sums (the GEMMs covered all B * Tp rows: no class rows of their own to finish)
+    const int cls_blocks = N < Tp ? (B + 3) / 4 : 0;
+    hipLaunchKernelGGL(ln_stats_kernel, dim3(patch_blocks + cls_blocks), dim3(256), 0, s, pstats, resid, rowstats, B, N, Tp, C, C / 64, eps,
                        patch_blocks);
     MHMR_CHECK_LAUNCH();
     return 0;

@@ -63,8 +63,10 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
     """SMPL-X arrays (keys of SMPLX_NEUTRAL.npz) -> mhmr_lbs_consts tensors.
 
     * blend basis rows = [posedirs (486) | shapedirs[:, :, :nb] | shapedirs[:, :, 300:310] | 0-pad], scaled by 2^10 into the f16
-      normal range and stored as an f16 pair hi + lo, tile-major [Vp/48][Kb/8][hi|lo][3][48][8] (48-vertex tiles = three MFMA
-      column blocks): one 16-byte line per lane is the 16x16x32 MFMA operand for 8 consecutive k; the template stays fp32 ([3][Vp]);
+      normal range, tile-major (48-vertex tiles = three MFMA column blocks; one 16-byte line per lane is the 16x16x32 MFMA operand for
+      8 consecutive k): per tile the k blocks 0..Kb/8-9 (k < 448: pose correctives, millimetres) as f16 [Kb/8-8][3][48][8] -- the HIGH
+      half alone, |error| <= 2^-12 |D| --, then the last eight k blocks (the last pose columns and every shape / expression direction)
+      as an f16 PAIR hi + lo [8][hi|lo][3][48][8] (fp32 accuracy); the template stays fp32 ([3][Vp]);
     * the dense joint regressor is pre-contracted with the template and the blend shapes (J = J0 + JS.coef);
     * skinning weights: the dense [64, Vp] matrix as an f16 pair hi + lo in MFMA operand order (``skin16``; the kernel blends the
       joint transforms as a GEMM), plus the K-sparse (index, weight) list, K = max non-zeros per vertex (tools / tests);
@@ -112,11 +114,16 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
         raise ValueError("blend basis x 2^10 leaves the f16 range")
     if not bool((np.abs(hi.astype(np.float64) + lo.astype(np.float64) - Ds) <= 2.0 ** -22 * np.abs(Ds) + 2.0 ** -25).all()):
         raise ValueError("blend basis: the f16 hi + lo pair does not reproduce the fp32 value")
-    # tile-major: the slice of one 48-vertex tile is ONE contiguous 288 KiB block [Kb/8][hi|lo][3][48][8] (the kernel DMAs it into
-    # LDS an eighth at a time: whole DRAM pages instead of 768-byte pieces 168 KB apart)
+    # tile-major: the slice of one 48-vertex tile is ONE contiguous 162 KiB block (the kernel DMAs it into LDS an eighth of the k
+    # range at a time: whole DRAM pages instead of 768-byte pieces 168 KB apart): [Kb/8 - 8][3][48][8] high halves, then the last
+    # eight k blocks as [8][hi|lo][3][48][8]
     T = LBS_TILE
     lay = lambda a: a.reshape(Kb // 8, 8, 3, Vp // T, T).transpose(3, 0, 2, 4, 1)           # [Vp/48, Kb/8, 3, 48, 8]
-    basis16 = np.ascontiguousarray(np.stack([lay(hi), lay(lo)], axis=2))                    # [Vp/48, Kb/8, 2, 3, 48, 8]
+    nt, kp = Vp // T, Kb // 8 - 8
+    if 8 * kp > 486:
+        raise ValueError("the pair part of the blend basis (last 64 k) must hold every shape / expression direction")
+    basis16 = np.ascontiguousarray(np.concatenate(
+        [lay(hi)[:, :kp].reshape(nt, -1), np.stack([lay(hi)[:, kp:], lay(lo)[:, kp:]], axis=2).reshape(nt, -1)], axis=1))   # [Vp/48, 82944]
     vtemp = np.zeros((3, Vp), dtype=np.float32)
     vtemp[:, live] = v_t.T[:, src[live]]
 

@@ -44,11 +44,13 @@ def hi_lo(w: torch.Tensor, tdt) -> torch.Tensor:
 
 
 def fold_eligible(C: int, N: int) -> bool:
-    """The LayerNorm fold (csrc/gemm256.hip, GemmArgs::pstats / rowstats) needs the token-row map: every block linear on the 256x256
-    kernel.  MHMR_LNFOLD=0 / MHMR_ROWMAP=0 switch it off (A/B measurements)."""
+    """The LayerNorm fold (csrc/gemm256.hip, GemmArgs::pstats / rowstats) needs every block linear on the 256x256 kernel: embed_dim a
+    multiple of 256 (ViT-B / ViT-L), and either the token-row map (N a multiple of 256) or, for any other N (1288^2: 8464), the rows
+    of an image padded to a multiple of 256 so that the GEMMs cover whole tiles of ALL rows (padded_tokens).  MHMR_LNFOLD=0 /
+    MHMR_ROWMAP=0 switch it off (A/B measurements)."""
     import os
     return (os.environ.get("MHMR_LNFOLD", "1") != "0" and os.environ.get("MHMR_ROWMAP", "1") != "0" and "MHMR_GEMM128" not in os.environ and
-            C % 256 == 0 and N % 256 == 0)
+            C % 256 == 0 and (N % 256 == 0 or os.environ.get("MHMR_LNFOLD_ALLROWS", "1") != "0"))
 
 
 def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = None, lnfold: bool | None = None) -> dict:
@@ -83,8 +85,8 @@ def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = N
     #   y = rstd (x16 . W'^T - mean colsum) + b',   W' = W diag(w_ln) (rounded to 16 bits AFTER the fold),  b' = b + W b_ln,
     #   colsum[n] = sum_k W'[n][k] over exactly the 16-bit values the matrix pipe multiplies (hi + lo where there is a low half)
     P["fold"] = fold_eligible(Cd, N) if lnfold is None else bool(lnfold)
-    if P["fold"] and not (Cd % 256 == 0 and N % 256 == 0):
-        raise ValueError("lnfold needs embed_dim and the patch count per image to be multiples of 256")
+    if P["fold"] and Cd % 256:
+        raise ValueError("lnfold needs embed_dim to be a multiple of 256")
 
     def folded(lin, norm, lo_rows=None):
         """-> (op16 W' [N, K], fp32 b' [N], fp32 colsum [N], hi|lo of rows lo_rows or None)"""
@@ -143,6 +145,8 @@ def padded_tokens(P: dict, B: int) -> int:
     (row_map), or embed_dim and B * Tp are multiples of 256; otherwise a multiple of 128, the row tile of the 128x128 kernel.
     896^2: 4160 instead of 4224 rows per image."""
     import os
+    if P.get("fold") and (P["T"] - 1) % 256:
+        return roundup(P["T"], 256)        # folded LayerNorms without the row map: whole 256-row tiles of all rows, for every batch size
     t64, t128 = roundup(P["T"], 64), roundup(P["T"], 128)
     # the predicate of csrc/gemm256.hip mhmr_gemm256_eligible for the residual GEMMs over all B * Tp rows (32-bit residual offsets),
     # and the switch that forces the 128x128 kernel everywhere
@@ -181,9 +185,9 @@ class WorkspaceCache:
         Bh = B // nsplit
         Cd, N, Tp, H = P["C"], P["N"], padded_tokens(P, Bh), P["H"]
         z = lambda *s, dtype=tdt: torch.zeros(*s, dtype=dtype, device=dev)
-        if P.get("fold") and not row_map(P, Bh):
-            raise _lib.MhmrError(f"batch {Bh} is too large for the token-row map this pack's folded LayerNorms need (32-bit residual offsets of "
-                                 "the 256x256 kernel); build the model with lnfold=False for such batches")
+        if P.get("fold") and Bh * Tp * Cd * 4 >= 2 ** 32:
+            raise _lib.MhmrError(f"batch {Bh} is too large for this pack's folded LayerNorms (32-bit residual offsets of the 256x256 kernel); "
+                                 "build the model with lnfold=False for such batches")
         v = P["vit"]
         parts = []
         for i in range(nsplit):

@@ -104,6 +104,16 @@ def main():
                     vs = cfg.get("vstride", 1)
                     for k, v in res.items():
                         out[k] = v[:, ::vs].numpy() if (vs > 1 and k in ("v3d", "v2d")) else v.numpy()
+                    if cfg.get("hostile"):
+                        # the NETWORK's own sensitivity: the reference (fp32, same weights) on the image rounded ONCE to f16 -- a
+                        # relative input perturbation of 2^-12.  sens_<key> = relative L2 change of that output.  An implementation
+                        # with 16-bit matrix operands makes ~10^2 roundings of this size along the path; where one of them already
+                        # moves an output by more than the 1e-3 contract, no such implementation can meet it, and the parity test
+                        # bounds the error by a multiple of this instead (tests/test_gpu_parity_fullsize.py)
+                        res2 = model(x.half().float(), idx=idx, K=K, is_training=True)
+                        for k, v in res.items():
+                            if v.dtype.is_floating_point and k != "rotvec":
+                                out["sens_" + k] = np.float64((res2[k].double() - v.double()).norm() / v.double().norm().clamp_min(1e-30))
                 else:
                     # choose the classifier bias + threshold so that a handful of tokens are detected, with the
                     # threshold centred in the widest score gap (no detection is within rounding of it)

@@ -610,12 +610,15 @@ def test_lbs_against_oracle(L, smplx_data, P, center):
     args = [d(pose), d(shape), d(expr), d(loc), d(dist), d(K), d(det_b, torch.int32)]
     _lib.check(L.mhmr_lbs_forward(C.byref(cs), *[a.data_ptr() for a in args], P, wsF.data_ptr(), wsA.data_ptr(), wsX.data_ptr(),
                                   v3d.data_ptr(), v2d.data_ptr(), j3d.data_ptr(), j2d.data_ptr(), transl.data_ptr(), stream()), "lbs")
-    for name, got in (("v3d", v3d), ("j3d", j3d), ("transl", transl)):
+    # metres.  Vertices (and the extra joints made of them): the pose correctives run as ONE f16 product per term (csrc/lbs.hip,
+    # LBS_EBYTES_HI: rms 4e-6 m, worst 2.5e-5 m on this synthetic basis whose correctives reach 8 cm), everything else at fp32 accuracy
+    for name, got, tol in (("v3d", v3d, 5e-5), ("j3d", j3d, 5e-5), ("transl", transl, 2e-5)):
         err = float((got.cpu() - ref[name]).abs().max())
-        assert err < 2e-5, (name, err)                        # metres
+        assert err < tol, (name, err)
+    assert float((j3d[:, :55].cpu() - ref["j3d"][:, :55]).abs().max()) < 2e-5          # the 55 posed joints do not pass through the blend
     for name, got in (("v2d", v2d), ("j2d", j2d)):
         err = float((got.cpu() - ref[name]).abs().max())
-        assert err < 5e-3, (name, err)                        # pixels
+        assert err < 1.5e-2, (name, err)                      # pixels
     assert float((j3d[:, [0]].cpu() - ref["transl_pelvis"]).abs().max()) < 2e-5
     # joints 55..75 are vertices picked by id: the extra-joint tiles of the vertex kernel (virtual vertices with corner weights (1, 0, 0))
     # must reproduce those vertices bit for bit, in 3D and in the image
@@ -659,8 +662,8 @@ def test_lbs_max_abs_gate_160_persons_x_20_seeds(L, smplx_data):
                                       v3d.data_ptr(), v2d.data_ptr(), j3d.data_ptr(), j2d.data_ptr(), transl.data_ptr(), stream()), "lbs")
         worst3 = max(worst3, float((v3d.cpu() - ref["v3d"]).abs().max()), float((j3d.cpu() - ref["j3d"]).abs().max()))
         worst2 = max(worst2, float((v2d.cpu() - ref["v2d"]).abs().max()), float((j2d.cpu() - ref["j2d"]).abs().max()))
-    assert worst3 < 2e-5, worst3           # metres
-    assert worst2 < 2e-2, worst2           # pixels at 1288^2 (focal ~1115 px: 2e-5 m at 2 m is 1e-2 px)
+    assert worst3 < 5e-5, worst3           # metres (one-product pose correctives: csrc/lbs.hip LBS_EBYTES_HI; 2e-5 before round 4)
+    assert worst2 < 4e-2, worst2           # pixels at 1288^2 (focal ~1115 px: 5e-5 m at 2 m is 3e-2 px)
 
 
 def test_attention_is_bit_reproducible(L):

@@ -53,12 +53,23 @@ def test_pack_smplx_is_an_exact_refactoring_of_smplx_lbs(smplx_data):
     pf = 0.1 * torch.randn(486, generator=g)
     F = torch.zeros(pk["Kb"], dtype=torch.float64)
     F[:486], F[486:506] = pf.double(), coef.double()
-    b16 = pk["basis16"].double()                                                  # [Vp/48, Kb/8, hi|lo, axis, 48, 8], scaled by 2^10
-    D = (b16[:, :, 0] + b16[:, :, 1]).permute(1, 4, 2, 0, 3).reshape(pk["Kb"], 3, pk["Vp"]) / 1024.0  # [k, axis, v]
+    # per tile: [Kb/8 - 8][axis][48][8] high halves of k < 448, then [8][hi|lo][axis][48][8] of the last 64 k; scaled by 2^10
+    b16 = pk["basis16"].double()
+    nt, kp = pk["Vp"] // 48, pk["Kb"] // 8 - 8
+    assert b16.shape == (nt, kp * 3 * 48 * 8 + 8 * 2 * 3 * 48 * 8) and pk["basis16"].dtype == torch.float16
+    head = b16[:, : kp * 1152].reshape(nt, kp, 3, 48, 8)
+    tail = b16[:, kp * 1152:].reshape(nt, 8, 2, 3, 48, 8)
+    Dt = torch.cat([head, tail[:, :, 0] + tail[:, :, 1]], dim=1)                               # [tile, k block, axis, 48, 8]
+    D = Dt.permute(1, 4, 2, 0, 3).reshape(pk["Kb"], 3, pk["Vp"]) / 1024.0                       # [k, axis, v]
     v_posed = (torch.einsum("k,kav->va", F, D) + pk["vtemp"].double().T)[: pk["V"]].float()
-    assert float((D.float() - D.half().float()).abs().max()) > 0 and pk["basis16"].dtype == torch.float16      # hi alone would not do
     ref = v_shaped + (pf @ bm.posedirs).view(-1, 3)
-    assert float((v_posed - ref).abs().max()) < 2e-6
+    # the pose correctives of k < 448 carry the f16 rounding of the basis (2^-12 relative per term: micrometres) ...
+    assert float((v_posed - ref).abs().max()) < 1e-5
+    # ... the shape / expression directions and the last pose columns are exact to fp32 (the pair form)
+    F2 = F.clone(); F2[:448] = 0
+    ref2 = torch.einsum("l,mkl->mk", coef, torch.cat([bm.shapedirs, bm.expr_dirs], -1)) + (pf[448:] @ bm.posedirs[448:]).view(-1, 3)
+    assert float((torch.einsum("k,kav->va", F2, D)[: pk["V"]].float() - ref2).abs().max()) < 2e-6
+    assert float((tail[:, :, 1]).abs().max()) > 0                                               # hi alone would not do there
     assert pk["Kinf"] == 4 and pk["Vp"] % 48 == 0 and pk["Kb"] % 32 == 0
     W = torch.zeros(pk["V"], 55).scatter_add_(1, pk["skin_idx"].long(), pk["skin_w"])
     assert torch.allclose(W, bm.lbs_weights, atol=0)
@@ -146,6 +157,10 @@ def test_token_rows_per_image_rule(monkeypatch):
     assert vit.padded_tokens({"C": 1024, "T": 2305}, 32) == 2368 and vit.padded_tokens({"C": 1024, "T": 2305}, 1) == 2368
     assert vit.padded_tokens({"C": 1024, "T": 8465}, 8) == 8512 and not vit.row_map({"C": 1024, "T": 8465}, 8)      # 1288^2: N = 8464
     assert vit.padded_tokens({"C": 1024, "T": 8465}, 1) == 8576
+    # ... and with folded LayerNorms but no row map (N = 8464 is not a multiple of 256): rows per image padded to whole 256-row tiles,
+    # whatever the batch size (the fold needs every block linear on the 256x256 kernel over all B * Tp rows)
+    assert all(vit.padded_tokens({"C": 1024, "T": 8465, "fold": True}, b) == 8704 for b in (1, 3, 8))
+    assert vit.padded_tokens({"C": 1024, "T": 4097, "fold": True}, 32) == 4160 and vit.fold_eligible(1024, 8464) and not vit.fold_eligible(384, 2304)
     assert vit.padded_tokens({"C": 384, "T": 2305}, 16) == 2432           # ViT-S: proj / fc2 / V run on the 128x128 kernel
     assert vit.padded_tokens({"C": 768, "T": 2305}, 16) == 2368           # ViT-B: 256-multiples throughout
     assert vit.padded_tokens({"C": 1024, "T": 257}, 8) == 320 and vit.padded_tokens({"C": 1024, "T": 257}, 2) == 320 and vit.row_map({"C": 1024, "T": 257}, 2)
@@ -231,6 +246,11 @@ def test_extra_joint_tiles_of_the_packed_body_model(smplx_data):
     V, Vl, Vp = pk["V"], pk["Vl"], pk["Vp"]
     assert Vl == packing.roundup(V, 48) and Vp == Vl + 5 * 48 and pk["basis16"].shape[0] == Vp // 48
     b16, s16, vt = pk["basis16"].numpy(), pk["skin16"].numpy(), pk["vtemp"].numpy()
+    kp = pk["Kb"] // 8 - 8
+
+    def col(v):          # every basis value of vertex column v: the high-half part and the pair part of its tile
+        t = b16[v // 48]
+        return np.concatenate([t[: kp * 1152].reshape(kp, 3, 48, 8)[:, :, v % 48].ravel(), t[kp * 1152:].reshape(8, 2, 3, 48, 8)[:, :, :, v % 48].ravel()])
     faces = np.asarray(smplx_data["f"]).astype(np.int64)
     corners = np.concatenate([np.repeat(np.asarray(constants.SMPLX_EXTRA_JOINT_VERTS)[:, None], 3, 1),
                               faces[np.asarray(smplx_data["lmk_faces_idx"]).astype(np.int64)]], 0)
@@ -238,12 +258,12 @@ def test_extra_joint_tiles_of_the_packed_body_model(smplx_data):
     for e in range(72):
         for k in range(3):
             vv, src = Vl + 48 * (e // 16) + 16 * k + e % 16, int(corners[e, k])
-            assert np.array_equal(b16[vv // 48][..., vv % 48, :], b16[src // 48][..., src % 48, :])
+            assert np.array_equal(col(vv), col(src))
             assert np.array_equal(s16[vv // 48][..., vv % 48, :], s16[src // 48][..., src % 48, :]) and np.array_equal(vt[:, vv], vt[:, src])
     xb = pk["xbary"].numpy()
     assert np.array_equal(xb[:21], np.tile([[1.0, 0.0, 0.0]], (21, 1))) and np.allclose(xb[21:], np.asarray(smplx_data["lmk_bary_coords"]))
     unused = [Vl + 48 * 4 + 16 * k + i for k in range(3) for i in range(8, 16)]           # slots 72..79 of the fifth tile
-    assert all(not b16[v // 48][..., v % 48, :].any() for v in unused)
+    assert all(not col(v).any() for v in unused)
 
 
 def test_bench_starts_its_own_ranks_and_refuses_more_gpus_than_the_node_has():

@@ -154,6 +154,8 @@ def main():
     torch.manual_seed(0)
     smplx_data, mean_params = synthetic.make_smplx_data(0), synthetic.make_mean_params(0)
     sd = synthetic.make_state_dict(a.backbone, a.img, seed=a.seed, mean_params=mean_params)
+    if a.golden_case:      # (incl. the hostile weight statistics of the *_hostile_* cases)
+        sd = make_golden.case_state_dict(make_golden.CASES[a.golden_case])
     ref = OracleModel(sd, smplx_data, backbone=a.backbone, img_size=a.img)
     g = torch.Generator().manual_seed(1000 + a.seed)
     x = torch.randn(1, 3, a.img, a.img, generator=g)
