@@ -523,13 +523,20 @@ class Model(nn.Module):
         def person_dicts(o, rows):
             return [dict(zip(keys, vals)) for vals in zip(*(o[n][:rows].unbind(0) for n in keys))]
 
+        import time as _t
+        trace = os.environ.get("MHMR_TRACE_HOST") is not None
         cap = self._person_cap.get(B)
         o = persons = None
         if cap is not None:
+            t0 = _t.perf_counter()
             o, det, info = detect_and_heads(cap)
-            if not batched:
+            t1 = _t.perf_counter()
+            if not batched and os.environ.get("MHMR_LATE_DICTS") is None:
                 persons = person_dicts(o, cap)
+            t2 = _t.perf_counter()
             Pn = int(info[3].item())                       # the host sync
+            if trace:
+                self._host_trace = getattr(self, "_host_trace", []) + [(t1 - t0, t2 - t1, _t.perf_counter() - t2, _t.perf_counter())]
             if Pn > cap:
                 o = persons = None
         else:
