@@ -499,44 +499,39 @@ class Model(nn.Module):
         k = int(nms_kernel_size)
         _lib.check(L.mhmr_detect_count(ws["scores"].data_ptr(), B, G, k, thr, ws["counts"].data_ptr(), stream), "mhmr_detect_count")
 
-        def detect_and_heads(cap):
-            det, scores_det, base = i32(3, cap), torch.zeros(cap, dtype=torch.float32, device=dev), i32(B)
-            gstart_t, chunks_t, info, ngc, ncc = tables(cap)
-            _lib.check(L.mhmr_person_groups(ws["counts"].data_ptr(), None, 0, B, cap, base.data_ptr(), gstart_t.data_ptr(), ngc,
-                                            chunks_t.data_ptr(), ncc, info.data_ptr(), stream), "mhmr_person_groups")
-            _lib.check(L.mhmr_detect_write_cap(ws["scores"].data_ptr(), B, G, k, thr, base.data_ptr(), det[0].data_ptr(), det[1].data_ptr(),
-                                               det[2].data_ptr(), scores_det.data_ptr(), cap, stream), "mhmr_detect_write_cap")
-            o = self._heads(P, ws, K, det, cap, gstart_t, ngc, chunks_t, ncc, info, stream)
-            o["scores"] = scores_det
-            return o, det, info
-
-        # Fixed capacity: the heads are enqueued for `cap` person rows (a little above the previous batch's count; rows behind the real
-        # persons are padding that the kernels compute and nobody reads), and the ONE host synchronisation -- the person count, which the
-        # reference takes in torch.where in the MIDDLE of its forward (model.py:146) -- comes after the last launch, when it costs the GPU
-        # nothing.  The first call, and a batch with more persons than the capacity, take the count first (exact sizes).
         # per-person dicts (model.py:329-347); v2d / rotmat are computed but not exposed, as in the reference.  One unbind per key
-        # instead of rows x 10 indexing calls (3 ms -> 1 ms of host time at 256 persons) -- and in the fixed-capacity path the dicts of
-        # ALL capacity rows are made BEFORE the count is read back, i.e. while the GPU is still busy with this forward: after the
-        # synchronisation only a list slice is left (views of padding rows are dropped unread).
+        # instead of rows x 10 indexing calls (3 ms -> 1 ms of host time at 256 persons).
         keys = self.PERSON_KEYS
 
         def person_dicts(o, rows):
             return [dict(zip(keys, vals)) for vals in zip(*(o[n][:rows].unbind(0) for n in keys))]
 
-        import time as _t
-        trace = os.environ.get("MHMR_TRACE_HOST") is not None
+        def detect_and_heads(cap, with_dicts):
+            det, scores_det, base = i32(3, cap), torch.zeros(cap, dtype=torch.float32, device=dev), i32(B)
+            gstart_t, chunks_t, info, ngc, ncc = tables(cap)
+            o = self._alloc_outputs(P, cap, dev)
+            o["scores"] = scores_det
+            # The dicts are VIEWS of the output buffers: they are made here, BEFORE the heads are enqueued -- the host is far ahead of the
+            # GPU at this point (the backbone has just been enqueued and runs for >100 ms; its launches are what the later ones queue
+            # behind), so this millisecond of host work is free, whereas after the last launch the GPU has only the ~1 ms tail left
+            # (measured: profiles/r04_session_c_inference_host_cfg5_cfg2.txt).  Dicts of padding rows are dropped unread.
+            persons = person_dicts(o, cap) if with_dicts else None
+            _lib.check(L.mhmr_person_groups(ws["counts"].data_ptr(), None, 0, B, cap, base.data_ptr(), gstart_t.data_ptr(), ngc,
+                                            chunks_t.data_ptr(), ncc, info.data_ptr(), stream), "mhmr_person_groups")
+            _lib.check(L.mhmr_detect_write_cap(ws["scores"].data_ptr(), B, G, k, thr, base.data_ptr(), det[0].data_ptr(), det[1].data_ptr(),
+                                               det[2].data_ptr(), scores_det.data_ptr(), cap, stream), "mhmr_detect_write_cap")
+            self._heads(P, ws, K, det, cap, gstart_t, ngc, chunks_t, ncc, info, stream, o)
+            return o, det, info, persons
+
+        # Fixed capacity: the heads are enqueued for `cap` person rows (a little above the previous batch's count; rows behind the real
+        # persons are padding that the kernels compute and nobody reads), and the ONE host synchronisation -- the person count, which the
+        # reference takes in torch.where in the MIDDLE of its forward (model.py:146) -- comes after the last launch, when it costs the GPU
+        # nothing.  The first call, and a batch with more persons than the capacity, take the count first (exact sizes).
         cap = self._person_cap.get(B)
         o = persons = None
         if cap is not None:
-            t0 = _t.perf_counter()
-            o, det, info = detect_and_heads(cap)
-            t1 = _t.perf_counter()
-            if not batched and os.environ.get("MHMR_LATE_DICTS") is None:
-                persons = person_dicts(o, cap)
-            t2 = _t.perf_counter()
+            o, det, info, persons = detect_and_heads(cap, not batched)
             Pn = int(info[3].item())                       # the host sync
-            if trace:
-                self._host_trace = getattr(self, "_host_trace", []) + [(t1 - t0, t2 - t1, _t.perf_counter() - t2, _t.perf_counter())]
             if Pn > cap:
                 o = persons = None
         else:
@@ -545,15 +540,26 @@ class Model(nn.Module):
         if Pn == 0:
             return (([] if not batched else {}), torch.zeros(0, dtype=torch.int32, device=dev)) if (with_ids or batched) else []
         if o is None:
-            o, det, info = detect_and_heads(Pn)
+            o, det, info, persons = detect_and_heads(Pn, not batched)
         ids = det[0][:Pn]
         if batched:
             return {n: o[n][:Pn] for n in keys}, ids
-        persons = persons[:Pn] if persons is not None else person_dicts(o, Pn)
+        persons = persons[:Pn]
         return (persons, ids) if with_ids else persons
 
-    def _heads(self, P, ws, K, det, Pn, gstart_t, ngc, chunks_t, ncc, info, stream):
-        """HPH (model.py:258-283, 287-298) + SMPL-X layer (model.py:319-321) for Pn person rows -> dict of batched tensors."""
+    def _alloc_outputs(self, P, Pn, dev):
+        """The output tensors of the heads for Pn person rows (views of them are what forward returns)."""
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        nb, V = P["hph"]["nb"], P["lbs"]["V"]
+        o = {"offset": f(Pn, 2), "loc": f(Pn, 2), "rotmat": f(Pn, 53, 3, 3), "rotvec": f(Pn, 53, 3), "shape": f(Pn, nb), "expression": f(Pn, 10),
+             "dist_postprocessed": f(Pn, 1), "dist": f(Pn, 1), "v3d": f(Pn, V, 3), "v2d": f(Pn, V, 2), "j3d": f(Pn, 127, 3), "j2d": f(Pn, 127, 2),
+             "transl": f(Pn, 3)}
+        o["transl_pelvis"] = o["j3d"][:, 0:1]             # [Pn, 1, 3] view of joint 0 (the reference: j3d[:, [0]])
+        return o
+
+    def _heads(self, P, ws, K, det, Pn, gstart_t, ngc, chunks_t, ncc, info, stream, o=None):
+        """HPH (model.py:258-283, 287-298) + SMPL-X layer (model.py:319-321) for Pn person rows -> dict of batched tensors (written
+        into ``o`` when the caller allocated them: _alloc_outputs)."""
         L = _lib.lib()
         dev, B, G, N, Cdim, Kc, dt = K.device, K.shape[0], P["G"], P["N"], P["C"], P["Kc"], P["dt_id"]
         h = P["hph"]
@@ -573,10 +579,10 @@ class Model(nn.Module):
             setattr(d, n, t.data_ptr())
         d.kv = ws["kv"].data_ptr()
         d.nvalid = info.data_ptr() if info is not None else None
-        offset, loc = f(Pn, 2), f(Pn, 2)
-        rotmat, rotvec = f(Pn, 53, 3, 3), f(Pn, 53, 3)
-        shape, expression = f(Pn, h["nb"]), f(Pn, 10)
-        dist_pp, dist = f(Pn, 1), f(Pn, 1)
+        if o is None:
+            o = self._alloc_outputs(P, Pn, dev)
+        offset, loc, rotmat, rotvec, shape, expression = o["offset"], o["loc"], o["rotmat"], o["rotvec"], o["shape"], o["expression"]
+        dist_pp, dist = o["dist_postprocessed"], o["dist"]
         # ngc / Pn / ncc are upper bounds of the group count, the largest group and the work-item count (include/mhmr.h)
         _lib.check(L.mhmr_hph_forward(C.byref(d), ws["feat32"].data_ptr(), ws["zK"].data_ptr(), ws["ctx16"].data_ptr(), det[0].data_ptr(),
                                       det[1].data_ptr(), det[2].data_ptr(), Pn, gstart_t.data_ptr(), ngc, Pn,
@@ -585,13 +591,10 @@ class Model(nn.Module):
                                       dist.data_ptr(), stream), "mhmr_hph_forward")
         lb = P["lbs"]
         V = lb["V"]
-        v3d, v2d = f(Pn, V, 3), f(Pn, V, 2)
-        j3d, j2d, transl = f(Pn, 127, 3), f(Pn, 127, 2), f(Pn, 3)
+        v3d, v2d, j3d, j2d, transl = o["v3d"], o["v2d"], o["j3d"], o["j2d"], o["transl"]
         ws_F, ws_A, ws_xf = f(roundup(Pn, 16), lb["Kb"]), f(roundup(Pn, 16), 768), f(Pn, 24)
         _lib.check(L.mhmr_lbs_forward(C.byref(P["lbs_struct"]), rotvec.data_ptr(), shape.data_ptr(), expression.data_ptr(), loc.data_ptr(),
                                       dist.data_ptr(), K.data_ptr(), det[0].data_ptr(), Pn, ws_F.data_ptr(), ws_A.data_ptr(),
                                       ws_xf.data_ptr(), v3d.data_ptr(), v2d.data_ptr(), j3d.data_ptr(), j2d.data_ptr(), transl.data_ptr(),
                                       stream), "mhmr_lbs_forward")
-        return {"offset": offset, "dist": dist, "dist_postprocessed": dist_pp, "expression": expression, "rotmat": rotmat,
-                "shape": shape, "rotvec": rotvec, "loc": loc, "v3d": v3d, "j3d": j3d, "j2d": j2d, "v2d": v2d,
-                "transl": transl, "transl_pelvis": j3d[:, [0]]}
+        return o
