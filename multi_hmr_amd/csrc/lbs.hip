@@ -35,6 +35,7 @@
 namespace {
 
 constexpr int NJ = 55;
+constexpr int LBS_KB_POSE = 512;      // = LBS_KB (declared below with the vertex kernel's constants; static_assert there)
 
 __device__ __forceinline__ void mat3_mul(const float* a, const float* b, float* c) {
 #pragma unroll
@@ -72,6 +73,9 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
                                                       float* __restrict__ transl_out) {
     __shared__ float sR[NJ][9], sJ[NJ][3], sRw[NJ][9], sTw[NJ][3], sX[33];
     __shared__ int sPar[NJ];
+    // the person's two operand rows are collected here and leave as 16-byte chunks (8 consecutive k / joints of one person are 8
+    // consecutive f16 of the fragment-major layouts): 2 + 2 x 1.5 wide stores per lane instead of ~50 two-byte ones (round 4)
+    __shared__ __attribute__((aligned(16))) float sF[LBS_KB_POSE], sA[12][64];
     const int p = blockIdx.x, j = threadIdx.x;
     // Both operands are stored FRAGMENT-MAJOR: the 64 lanes of a wave read one (person group, part, k step) fragment as 1 KiB of
     // consecutive bytes (16 B per lane, lane = 16 * (k group) + person-in-group), i.e. eight whole 128-byte lines per wave
@@ -79,21 +83,39 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
     // not the matrix pipe or HBM, then paces the vertex kernel (93 us at 160 persons).
     //   F16 [group][hi|lo][Kb/32][64 lanes][8]      A16 [12 comps][hi|lo][group][2][64 lanes][8]
     const int ngr = Pp / 16, grp = p >> 4, pin = p & 15, nst = c.Kb / 32;
-    auto put_f = [&](int k, float v) {
-        const _Float16 h = (_Float16)v;
-        _Float16* f = F16 + ((((size_t)grp * 2) * nst + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + pin) * 8 + (k & 7);
-        f[0] = h;
-        f[(size_t)nst * 512] = (_Float16)(v - (float)h);
-    };
-    auto put_a = [&](int comp, int joint, float v) {
-        const _Float16 h = (_Float16)v;
-        _Float16* a = A16 + (((((size_t)comp * 2) * ngr + grp) * 2 + (joint >> 5)) * 64 + ((joint >> 3) & 3) * 16 + pin) * 8 + (joint & 7);
-        a[0] = h;
-        a[(size_t)ngr * 1024] = (_Float16)(v - (float)h);
+    auto put_f = [&](int k, float v) { sF[k] = v; };
+    auto put_a = [&](int comp, int joint, float v) { sA[comp][joint] = v; };
+    // chunk kb (k = 8 kb .. 8 kb + 7) of the feature row / chunk (comp, jb) of the transform rows -> hi and lo halves, 16 bytes each
+    typedef Op<MHMR_DT_F16>::V8 H8;
+    auto flush = [&](bool zero) {
+        for (int kb = j; kb < c.Kb / 8; kb += 64) {
+            H8 h, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = zero ? 0.f : sF[8 * kb + e];
+                h[e] = (_Float16)v;
+                l[e] = (_Float16)(v - (float)h[e]);
+            }
+            _Float16* f = F16 + ((((size_t)grp * 2) * nst + (kb >> 2)) * 64 + (kb & 3) * 16 + pin) * 8;
+            *(H8*)f = h;
+            *(H8*)(f + (size_t)nst * 512) = l;
+        }
+        for (int ch = j; ch < 96; ch += 64) {
+            const int comp = ch >> 3, jb = ch & 7;
+            H8 h, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = zero ? 0.f : sA[comp][8 * jb + e];
+                h[e] = (_Float16)v;
+                l[e] = (_Float16)(v - (float)h[e]);
+            }
+            _Float16* a = A16 + (((((size_t)comp * 2) * ngr + grp) * 2 + (jb >> 2)) * 64 + (jb & 3) * 16 + pin) * 8;
+            *(H8*)a = h;
+            *(H8*)(a + (size_t)ngr * 1024) = l;
+        }
     };
     if (p >= P) {  // padding rows of both operand matrices
-        for (int k = j; k < c.Kb; k += 64) put_f(k, 0.f);
-        for (int comp = 0; comp < 12; ++comp) put_a(comp, j, 0.f);
+        flush(true);
         return;
     }
     const int ncoef = c.nb + 10;
@@ -273,6 +295,8 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
         j2d[((size_t)p * 127 + j) * 2] = pr[0];
         j2d[((size_t)p * 127 + j) * 2 + 1] = pr[1];
     }
+    __syncthreads();
+    flush(false);
 }
 
 #ifdef MHMR_LBS_STAMPS      // tools/lbs_timeline.py: per-workgroup s_memtime stamps of wave 0 (debug build only, never in libmhmr.so)
@@ -322,6 +346,7 @@ constexpr int LBS_LDS = LBS_RING * LBS_EBYTES + LBS_NC * 16 * LBS_XREC;
 static_assert(LBS_EBYTES % (1024 * LBS_NL) == 0 && LBS_EOPS == 18 && LBS_EOPS_HI == 9 && LBS_WBYTES / 1024 / LBS_NL == 6 && LBS_RING == 3,
               "the landing waits below are written for 9 / 18 copies per wave and eighth, 6 for the weights, one eighth ahead");
 static_assert(LBS_LDS <= 160 * 1024, "LDS");
+static_assert(LBS_KB_POSE == LBS_KB, "pose kernel staging");
 
 __device__ __forceinline__ void lbs_barrier() {
     asm volatile("" ::: "memory");

@@ -12,7 +12,10 @@ depth = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 cfg = dict(make_golden.CASES["vitl_224_train"]); cfg["depth_override"] = depth
 sm, mp = synthetic.make_smplx_data(0), synthetic.make_mean_params(0)
 x, K, idx = make_golden.case_inputs(cfg)
-xc = x.cuda()
+# MHMR_SOAK_BATCH images (the case's two, repeated); with MHMR_SPLIT=n the backbone of every model runs n image blocks on side
+# streams of its own (model.Model._run_backbone): 2 host threads x n streams each
+nb = int(os.environ.get("MHMR_SOAK_BATCH", "2"))
+xc = x.repeat((nb + 1) // 2, 1, 1, 1)[:nb].contiguous().cuda()
 def build(seed):
     sd = synthetic.make_state_dict(cfg["backbone"], cfg["img_size"], seed=seed, depth_override=depth)
     m = Model(backbone=cfg["backbone"], img_size=cfg["img_size"], smplx_data=sm, mean_params=mp, backbone_depth=depth, precision="f16")
@@ -22,7 +25,10 @@ models = [build(2), build(91)]
 NAMES = ("resid", "xn", "qk", "vt", "att", "hid", "pstats", "rowstats", "feat32")
 def snap(m):
     ws = m._workspace(m._packed, xc.shape[0])
-    return {k: ws[k].clone() for k in NAMES if k in ws}
+    out = {"feat32": ws["feat32"].clone()}
+    for i, part in enumerate(ws["parts"]):
+        out.update({f"{k}[{i}]": part["bufs"][k].clone() for k in NAMES if k in part["bufs"]})
+    return out
 serial = []
 NBAD = [0]
 for m in models:
@@ -50,4 +56,5 @@ def worker(i):
 for s in streams: s.wait_stream(torch.cuda.current_stream())
 ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
 [t.start() for t in ts]; [t.join() for t in ts]
-print("done depth", depth, "lib", _lib.LIB_PATH, "mismatching forwards", NBAD[0])
+print("done depth", depth, "batch", nb, "image blocks", models[0]._nsplit(nb), "reps", os.environ.get('REPS', '10'), "source", _lib.lib().mhmr_source_hash().decode(),
+      "mismatching forwards", NBAD[0])
