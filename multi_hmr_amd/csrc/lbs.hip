@@ -310,9 +310,9 @@ __device__ unsigned long long* g_lbs_stamps;
 #endif
 // grid = Vp / 48 workgroups (one 48-vertex tile = three 16-vertex MFMA column blocks, for ALL persons of the launch) of
 // LBS_NC compute waves + LBS_NL loader waves; at most one workgroup per CU (126 KB of LDS).
-//   * loader waves do nothing but move the tile's slice of the blend basis (162 KiB) through a 3-slot LDS ring of k eighths
-//     (18 KiB each, 36 KiB the last one) with global_load_lds: two eighths are always in flight, so HBM never waits for a barrier; their vmcnt stream
-//     holds only these copies, so the landing wait is an exact count.  They also bring the persons' [R0 | translation | K]
+//   * loader waves do nothing but move the tile's slice of the blend basis (162 KiB) into LDS, an eighth of the k range at a time
+//     (18 KiB each, 36 KiB the last one) with global_load_lds: four to five eighths are always in flight (LBS_LEAD), so HBM never waits
+//     for a barrier; their vmcnt stream holds only these copies, so the landing wait is an exact count.  They also bring the persons' [R0 | translation | K]
 //     records into LDS once.
 //   * compute wave w owns person group g0 + w (16 persons).  Its A operands (F16, A16: L2-resident, the same for every tile) are
 //     ordinary loads one k step / one component ahead of their MFMAs; every loaded A fragment is multiplied against all THREE
@@ -328,7 +328,7 @@ constexpr int LBS_NC = 10, LBS_NL = 2;                 // compute waves (one per
 constexpr int LBS_KB = 512;                            // padded blend depth (486 pose + betas + 10 expression <= 512)
 constexpr int LBS_NX = 72;                             // extra joints 55..126 (virtual vertices in the tiles from c.Vl on)
 constexpr int LBS_NS = LBS_KB / 32;                    // k steps of 32
-constexpr int LBS_NE = 8, LBS_RING = 3;                // k eighths (2 steps each), LDS ring slots (4 slots: measured no faster at 1 / 20 / 160 persons)
+constexpr int LBS_NE = 8;                              // k eighths (2 steps each)
 constexpr int LBS_ROW = LBS_TV * 8 * 2;                // bytes of one (k block, part, axis) row of the tile: 48 vertices x 8 k x f16
 constexpr int LBS_EBYTES = (LBS_KB / 8 / LBS_NE) * 6 * LBS_ROW;       // one ring slot = one eighth of the tile's slice as an f16 PAIR: 36 KiB
 constexpr int LBS_EOPS = LBS_EBYTES / 1024 / LBS_NL;                  // 1-KiB copies per loader wave per eighth (pair form)
@@ -342,9 +342,18 @@ constexpr int LBS_EOPS_HI = LBS_EOPS / 2;
 constexpr int LBS_TILE_BYTES = (LBS_NE - 1) * LBS_EBYTES_HI + LBS_EBYTES;   // basis bytes of one tile: 162 KiB
 constexpr int LBS_WBYTES = 8 * 2 * LBS_TV * 8 * 2;     // the tile's dense skin weights, hi + lo: 12 KiB
 constexpr int LBS_XREC = 24 * 4;                       // bytes of one person's record in ws_xf
-constexpr int LBS_LDS = LBS_RING * LBS_EBYTES + LBS_NC * 16 * LBS_XREC;
-static_assert(LBS_EBYTES % (1024 * LBS_NL) == 0 && LBS_EOPS == 18 && LBS_EOPS_HI == 9 && LBS_WBYTES / 1024 / LBS_NL == 6 && LBS_RING == 3,
-              "the landing waits below are written for 9 / 18 copies per wave and eighth, 6 for the weights, one eighth ahead");
+// LDS image of the tile's slice (round 4: no ring any more).  With the high halves alone the first seven eighths are 18 KiB each and
+// ALL fit: every one has a slot of its own, five are requested before the first barrier (two more as the vmcnt budget of 63 allows), so
+// at small person counts -- where the kernel is nothing but this stream -- HBM sees up to 90 KiB per workgroup in flight instead of 36.
+// The last eighth (pair form, 36 KiB) re-uses the slots of eighths 0 and 1, the skin weights (12 KiB) the slot of eighth 2.
+constexpr int LBS_LEAD = 5;                                            // eighths requested before the first barrier
+__host__ __device__ constexpr int lbs_eoff(int e) { return e < LBS_NE - 1 ? e * LBS_EBYTES_HI : 0; }
+constexpr int LBS_WOFF = 2 * LBS_EBYTES_HI;                            // the skin weights' place
+constexpr int LBS_XOFF = (LBS_NE - 1) * LBS_EBYTES_HI;                 // the person records behind the seven slots
+constexpr int LBS_LDS = LBS_XOFF + LBS_NC * 16 * LBS_XREC;
+static_assert(LBS_EBYTES % (1024 * LBS_NL) == 0 && LBS_EOPS == 18 && LBS_EOPS_HI == 9 && LBS_WBYTES / 1024 / LBS_NL == 6 && LBS_NE == 8 &&
+              LBS_LEAD == 5 && LBS_WBYTES <= LBS_EBYTES_HI,
+              "the landing waits below are written for 9 / 18 copies per wave and eighth, 6 for the weights, five eighths ahead");
 static_assert(LBS_LDS <= 160 * 1024, "LDS");
 static_assert(LBS_KB_POSE == LBS_KB, "pose kernel staging");
 
@@ -358,7 +367,7 @@ __device__ __forceinline__ void lbs_barrier() {
 __device__ __forceinline__ void lbs_loader(const mhmr_lbs_consts& c, const float* __restrict__ xf, int P, int ngroups, int g0, char* smem,
                                            int lw) {
     const int lane = threadIdx.x & 63;
-    char* xrec = smem + LBS_RING * LBS_EBYTES;
+    char* xrec = smem + LBS_XOFF;
     for (int i = lw; i < LBS_NC; i += LBS_NL) {
         const int g = g0 + i;
         if (g >= ngroups) break;
@@ -371,7 +380,7 @@ __device__ __forceinline__ void lbs_loader(const mhmr_lbs_consts& c, const float
     // tile-major basis: the tile's slice is one contiguous block, an eighth is 36 consecutive KiB; source and LDS image lane-linear
     const _Float16* bsrc = (const _Float16*)c.basis16 + (size_t)blockIdx.x * (LBS_TILE_BYTES / 2) + lane * 8;
     auto dma_e = [&](int e) {          // (e is a compile-time value at every call: the loops around are unrolled)
-        char* dst = smem + (e % LBS_RING) * LBS_EBYTES;
+        char* dst = smem + lbs_eoff(e);
         const int nops = e == LBS_NE - 1 ? LBS_EOPS : LBS_EOPS_HI;
 #pragma unroll
         for (int k = 0; k < LBS_EOPS; ++k) {
@@ -382,26 +391,29 @@ __device__ __forceinline__ void lbs_loader(const mhmr_lbs_consts& c, const float
         }
     };
 #pragma unroll
-    for (int e = 0; e < LBS_RING - 1; ++e) dma_e(e);
-    constexpr int EW = LBS_NE - LBS_RING + 1;            // the eighth at whose top the weights are requested (its slot: no later eighth's)
+    for (int e = 0; e < LBS_LEAD; ++e) dma_e(e);
     constexpr int WOPS = LBS_WBYTES / 1024 / LBS_NL;
 #pragma unroll
     for (int e = 0; e < LBS_NE; ++e) {
-        // eighth e (and everything older: the records) has landed when at most the copies requested after it are outstanding:
-        // the up to LBS_RING - 2 following eighths and, once requested, the weights
-        // (LBS_RING == 3: the one following eighth -- 9 copies, 18 for the last eighth -- ; the weights are requested at e == EW and
-        // published together with the last eighth by its vmcnt(0))
-        const int younger = e + 1 < LBS_NE ? (e + 1 == LBS_NE - 1 ? LBS_EOPS : LBS_EOPS_HI) : 0;
-        if (younger == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-        else if (younger == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        // eighth e (and everything older: the records) has landed when at most the copies requested AFTER it are outstanding (this
+        // wave's vmcnt stream holds nothing but these copies, and loads are counted in order).  Requests: eighths 0..4 up front; after
+        // barrier 0 / 1 eighths 5 / 6 (own slots); after barrier 2 the last eighth (18 copies, into the slots of eighths 0 and 1, read
+        // for the last time before barriers 1 and 2); after barrier 3 the weights (6 copies, the slot of eighth 2).
+        //   e:        0   1   2   3             4                 5             6        7
+        //   younger:  36  36  36  27 + 18 = 45  18 + 18 + 6 = 42  9 + 18 + 6    18 + 6   (0: the weights are published with it)
+        if (e <= 2) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+        else if (e == 3) asm volatile("s_waitcnt vmcnt(45)" ::: "memory");
+        else if (e == 4) asm volatile("s_waitcnt vmcnt(42)" ::: "memory");
+        else if (e == 5) asm volatile("s_waitcnt vmcnt(33)" ::: "memory");
+        else if (e == 6) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lbs_barrier();                                   // ... and every compute wave is done with eighth e - 1: its slot is free
-        if (e + LBS_RING - 1 < LBS_NE) dma_e(e + LBS_RING - 1);
-        else if (e == EW) {
-            // the tile's dense skin weights (12 KiB, tile-major [8 joint blocks][hi|lo][48][8] = MFMA operand order) take the slot no
-            // further eighth needs; the last landing wait (vmcnt(0)) and barrier publish them together with eighth 7
+        lbs_barrier();                                   // ... and every compute wave is done with eighth e - 1
+        if (e + LBS_LEAD < LBS_NE) dma_e(e + LBS_LEAD);
+        else if (e == 3) {
+            // the tile's dense skin weights (12 KiB, tile-major [8 joint blocks][hi|lo][48][8] = MFMA operand order); the last landing
+            // wait (vmcnt(0)) and barrier publish them together with eighth 7
             const _Float16* wsrc = (const _Float16*)c.skin16 + (size_t)blockIdx.x * (LBS_WBYTES / 2) + lane * 8;
-            char* dst = smem + (LBS_NE % LBS_RING) * LBS_EBYTES;
+            char* dst = smem + LBS_WOFF;
 #pragma unroll
             for (int k = 0; k < WOPS; ++k) {
                 const int i = lw * WOPS + k;
@@ -453,7 +465,7 @@ __device__ __forceinline__ void lbs_compute(const mhmr_lbs_consts& c, const _Flo
         LBS_STAMP(1 + e);
         const bool pair = e == LBS_NE - 1;                   // compile-time after unrolling
         const int rows = pair ? 6 : 3;                       // (part, axis) rows per k block of this eighth
-        const char* slot = smem + (e % LBS_RING) * LBS_EBYTES + g4 * (rows * LBS_ROW) + l15 * 16;     // + (4 s2) * rows + (part * 3 + axis) rows + st * 256
+        const char* slot = smem + lbs_eoff(e) + g4 * (rows * LBS_ROW) + l15 * 16;     // + (4 s2) * rows + (part * 3 + axis) rows + st * 256
         H8 B[2][6];
         auto read_b = [&](int set, int j) {           // j = 3 * s2 + st: the (part, axis) fragments of one vertex block of one k step
             const char* b = slot + (j / 3) * (4 * rows * LBS_ROW) + (j % 3) * 256;
@@ -497,7 +509,7 @@ __device__ __forceinline__ void lbs_compute(const mhmr_lbs_consts& c, const _Flo
     }
     // B operand of the skinning GEMM = the tile's dense skin weights, from LDS (loader): lane (v = l15, k group g4) of vertex block st
     // holds joints 8 (4 t + g4) + 0..7; [set][wh t0, wh t1, wl t0, wl t1], one block ahead
-    const char* wlds = smem + (LBS_NE % LBS_RING) * LBS_EBYTES + g4 * (2 * LBS_ROW) + l15 * 16;
+    const char* wlds = smem + LBS_WOFF + g4 * (2 * LBS_ROW) + l15 * 16;
     H8 W[2][4];
     auto read_w = [&](int set, int st) {
 #pragma unroll
@@ -538,7 +550,7 @@ __device__ __forceinline__ void lbs_compute(const mhmr_lbs_consts& c, const _Flo
     }
     LBS_STAMP(10);
     // ---- camera translation (fp32, exactly where the reference adds it: smpl_layer.py:139-140), projection, stores ----
-    const char* xrec = smem + LBS_RING * LBS_EBYTES + w * (16 * LBS_XREC);
+    const char* xrec = smem + LBS_XOFF + w * (16 * LBS_XREC);
     if (v0 < c.Vl) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
