@@ -536,7 +536,9 @@ class Model(nn.Module):
                 o = persons = None
         else:
             Pn = int(ws["counts"].sum().item())            # the host sync (first call)
-        self._person_cap[B] = roundup(max(Pn + Pn // 4 + 8, 32), 32)
+        # next capacity: an eighth above this batch's count (a batch that detects more than that re-runs its heads at the exact size,
+        # which costs what the reference's mid-forward count always costs); whole 16-person groups of the SMPL-X layer
+        self._person_cap[B] = roundup(max(Pn + max(Pn // 8, 8), 16), 16)
         if Pn == 0:
             return (([] if not batched else {}), torch.zeros(0, dtype=torch.int32, device=dev)) if (with_ids or batched) else []
         if o is None:
