@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define MHMR_VERSION 103   /* 103: mhmr_lbs_consts.basis16 layout (high halves for k < Kb - 64); mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
+#define MHMR_VERSION 103   /* 103: mhmr_camera_embed(num_bands), mhmr_hph_desc.cam_dim; mhmr_lbs_consts.basis16 layout (high halves for k < Kb - 64); mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
 
 #define MHMR_OK 0
 #define MHMR_ERR_BAD_ARG (-1)
@@ -186,10 +186,12 @@ int mhmr_person_groups(const int* counts, const int* det_b, int P, int B, int ca
                        int* chunks, int nchunks_cap, int* info, void* stream);
 
 /* Camera embedding.  Replaces Model.embedd_camera (model.py:160-187) + inverse_perspective_projection
- * (utils/camera.py:30-48) + FourierPositionEncoding (blocks/camera_embed.py:9-58).  zK: [B*N, 99] fp32; also
- * writes op16 copies to ctx16[:, C:C+99] and zeros ctx16[:, C+99:ldctx].  freq: [3*16] linspace(1, 32, 16) x3.   */
+ * (utils/camera.py:30-48) + FourierPositionEncoding (blocks/camera_embed.py:9-58) with num_bands frequency bands per ray component
+ * (model.py:39 camera_embedding_num_bands; <= 20): E = 3 + 6 num_bands channels (99 for the released checkpoints' 16).  zK: [B*N, E]
+ * fp32; also writes op16 copies to ctx16[:, C:C+E] and zeros ctx16[:, C+E:ldctx] (ldctx - C <= 128).  freq: [3*num_bands] =
+ * linspace(1, max_resolution / 2, num_bands) x3.                                                                     */
 int mhmr_camera_embed(const float* K, const float* freq, int B, int G, int patch, float* zK, void* ctx16, int ldctx,
-                      int C, int dtype, void* stream);
+                      int C, int dtype, int num_bands, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Human Perception Head.  Replaces HPH.cross_attn_inputs / HPH.forward (model.py:479-593), TransformerDecoder
@@ -212,16 +214,16 @@ typedef struct {
 typedef struct {
     int dtype;
     int C, G, N;                 /* backbone dim, grid, tokens per image                                      */
-    int Kc;                      /* context operand width: C + 99 rounded up to a multiple of 64             */
+    int Kc;                      /* context operand width: C + E (E = cam_dim) rounded up to a multiple of 64 */
     int dim, heads, mlp, depth;  /* 1024, xat_num_heads, 1024, xat_depth (model.py:122-126)                   */
     int nb;                      /* num_betas                                                                */
-    int Ktok;                    /* token width C + 99 + 318 + nb + 3 rounded up to a multiple of 16         */
+    int Ktok;                    /* token width C + E + 318 + nb + 3 rounded up to a multiple of 16          */
     int Ndec;                    /* 318 + nb + 3 + 10                                                        */
     int patch;                   /* 14                                                                       */
     int nearness;                /* model.py:196                                                             */
     float fn;                    /* S / (2 tan(30 deg)): focal length of the normalising 60-degree camera (utils/camera.py:71-77) */
     const float *off1_w, *off1_b, *off2_w, *off2_b; /* mlp_offset.{0,2}: [C,C],[C],[2,C],[2]                  */
-    const float *cq_x, *cq_y, *cv_x, *cv_y;         /* cross_{queries,values}_{x,y}: [G, C+99]                */
+    const float *cq_x, *cq_y, *cv_x, *cv_y;         /* cross_{queries,values}_{x,y}: [G, C+E]                 */
     const float* init_tail;      /* [318 + nb + 3] = init_body_pose | init_betas | init_cam                   */
     const float *tok_w, *tok_b;  /* to_token_embedding: [dim, Ktok] (zero padded), [dim] (+ pos_embedding[:,0]) */
     const mhmr_hph_layer* layers;/* HOST array of `depth`                                                    */
@@ -240,9 +242,10 @@ typedef struct {
      * (mhmr_person_groups' info[0]); rows behind it are padding -- computed like persons, never allowed to touch the context operand.
      * NULL = all P rows are persons. */
     const int* nvalid;
+    int cam_dim;    /* camera embedding channels E = 3 + 6 num_bands (0 = 99): context width C + E <= Kc, zK rows of E floats */
 } mhmr_hph_desc;
 
-/* Inputs: feat32 [B*N, C], zK [B*N, 99], ctx16 op16 [Mctx, Kc] (features | camera | 0), detections det_{b,y,x}
+/* Inputs: feat32 [B*N, C], zK [B*N, E], ctx16 op16 [Mctx, Kc] (features | camera | 0), detections det_{b,y,x}
  * [P] (sorted by (b, y, x)), gstart [ngroups+1] = person offsets of the non-empty images, chunks [nchunks*3] =
  * (image b, first person, count <= 8) cross-attention work items, K [B,3,3].  ngroups / nmax / nchunks size the launches and may be
  * UPPER BOUNDS when the tables come from mhmr_person_groups (empty groups and count-0 work items return at once).

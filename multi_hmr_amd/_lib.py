@@ -118,7 +118,8 @@ class HphDesc(C.Structure):
                                    "nearness")] + [("fn", _f)] +
                 [(n, _vp) for n in ("off1_w", "off1_b", "off2_w", "off2_b", "cq_x", "cq_y", "cv_x", "cv_y", "init_tail",
                                     "tok_w", "tok_b")] + [("layers", C.POINTER(HphLayer))] +
-                [(n, _vp) for n in ("dec_w", "dec_b", "zc", "token", "x", "xn", "t1", "t2", "kv", "dec", "det_row", "nvalid")])
+                [(n, _vp) for n in ("dec_w", "dec_b", "zc", "token", "x", "xn", "t1", "t2", "kv", "dec", "det_row", "nvalid")] +
+                [("cam_dim", _i)])
 
 
 class LbsConsts(C.Structure):
@@ -144,7 +145,7 @@ _SIGS = {
     "mhmr_detect_write": ([_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "mhmr_detect_write_cap": ([_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp], _i),
     "mhmr_person_groups": ([_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp], _i),
-    "mhmr_camera_embed": ([_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp], _i),
+    "mhmr_camera_embed": ([_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mhmr_hph_forward": ([C.POINTER(HphDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i,
                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "mhmr_xattn_layers_forward": ([C.POINTER(HphLayer)] + [_i] * 8 + [_vp] * 7 + [_i, _i, _vp, _i, _i, _vp], _i),

@@ -20,8 +20,8 @@ int mhmr_launch_scores(const void* hid, int ld, const float* w2, const float* b2
 int mhmr_launch_detect_count(const float* scores, int B, int G, int nms_kernel, float thr, int* counts, hipStream_t s);
 int mhmr_launch_detect_write(const float* scores, int B, int G, int nms_kernel, float thr, const int* base, int* det_b, int* det_y, int* det_x, float* det_score, int cap, hipStream_t s);
 int mhmr_launch_person_groups(const int* counts, const int* det_b, int P, int B, int cap, int* base, int* gstart, int ngcap, int* chunks, int nccap, int* info, hipStream_t s);
-int mhmr_launch_camera_embed(const float* Kmat, const float* freq, int B, int G, int patch, float* zK, void* ctx16, int Kc, int C, int dtype, hipStream_t s);
-int mhmr_launch_hph_inputs(const float* feat32, const float* zK, const int* det_b, const int* det_y, const int* det_x, const float* cq_x, const float* cq_y, const float* cv_x, const float* cv_y, const float* init_tail, int ntail, float* zc, float* token, int Ktok, void* ctx16, int Kc, int* det_row, int P, int G, int C, int dtype, const int* nvalid, hipStream_t s);
+int mhmr_launch_camera_embed(const float* Kmat, const float* freq, int B, int G, int patch, float* zK, void* ctx16, int Kc, int C, int dtype, int nbands, hipStream_t s);
+int mhmr_launch_hph_inputs(const float* feat32, const float* zK, const int* det_b, const int* det_y, const int* det_x, const float* cq_x, const float* cq_y, const float* cv_x, const float* cv_y, const float* init_tail, int ntail, float* zc, float* token, int Ktok, void* ctx16, int Kc, int* det_row, int P, int G, int C, int dtype, const int* nvalid, int cam_dim, hipStream_t s);
 int mhmr_launch_hph_self_attn(const float* qkv, const int* gstart, float* out, int ngroups, int nmax, int heads, hipStream_t s);
 int mhmr_launch_hph_cross_attn(const float* q, const float* kv, const int* chunks, int nchunks, float* out, int heads, int N, hipStream_t s);
 int mhmr_launch_hph_decode(const float* dec, int ldd, int nb, const float* Kmat, const int* det_b, float fn, int nearness, float* rotmat, float* rotvec, float* betas, float* expr, float* dist_pp, float* dist, int P, hipStream_t s);
@@ -309,8 +309,8 @@ int mhmr_person_groups(const int* counts, const int* det_b, int P, int B, int ca
     return mhmr_launch_person_groups(counts, det_b, P, B, cap, base, gstart, ngroups_cap, chunks, nchunks_cap, info, (hipStream_t)stream);
 }
 int mhmr_camera_embed(const float* K, const float* freq, int B, int G, int patch, float* zK, void* ctx16, int ldctx, int C,
-                      int dtype, void* stream) {
-    return mhmr_launch_camera_embed(K, freq, B, G, patch, zK, ctx16, ldctx, C, dtype, (hipStream_t)stream);
+                      int dtype, int num_bands, void* stream) {
+    return mhmr_launch_camera_embed(K, freq, B, G, patch, zK, ctx16, ldctx, C, dtype, num_bands, (hipStream_t)stream);
 }
 int mhmr_linear_f32(const float* X, int ldx, const int* row_idx, const float* W, int ldw, const float* bias, const float* R,
                     int ldr, float* Y, int ldy, int M, int N, int K, int act, void* stream) {
@@ -370,7 +370,8 @@ int mhmr_hph_forward(const mhmr_hph_desc* d, const float* feat32, const float* z
 
     // queries, mlp_offset input, context rows of the detected cells  (model.py:255-265, 500-517, 541-552)
     TRY(mhmr_launch_hph_inputs(feat32, zK, det_b, det_y, det_x, d->cq_x, d->cq_y, d->cv_x, d->cv_y, d->init_tail,
-                               318 + d->nb + 3, d->zc, d->token, d->Ktok, ctx16, d->Kc, d->det_row, P, d->G, C, d->dtype, d->nvalid, s));
+                               318 + d->nb + 3, d->zc, d->token, d->Ktok, ctx16, d->Kc, d->det_row, P, d->G, C, d->dtype, d->nvalid,
+                               d->cam_dim > 0 ? d->cam_dim : 99, s));
     // mlp_offset (model.py:258) and loc (272-275)
     TRY(mhmr_launch_linear_f32(d->zc, C, nullptr, d->off1_w, C, d->off1_b, nullptr, 0, d->t1, C, P, C, C, MHMR_ACT_RELU, s));
     TRY(mhmr_launch_linear_f32(d->t1, C, nullptr, d->off2_w, C, d->off2_b, nullptr, 0, offset, 2, P, 2, C, MHMR_ACT_NONE, s));

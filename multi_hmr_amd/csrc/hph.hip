@@ -292,9 +292,10 @@ __device__ __forceinline__ void inv3x3(const float* k, float* o) {
 template <int DT>
 __global__ __launch_bounds__(128) void camera_embed_kernel(const float* __restrict__ Kmat, const float* __restrict__ freq,
                                                            int G, int patch, float* __restrict__ zK, void* __restrict__ ctx16_,
-                                                           int Kc, int C) {
+                                                           int Kc, int C, int nbands) {
     typedef typename Op<DT>::T T;
     const int N = G * G;
+    const int E = 3 + 6 * nbands;            // FourierPositionEncoding.channels (blocks/camera_embed.py:19-29): 99 for 16 bands
     const int row = blockIdx.x;  // b*N + n
     const int b = row / N, n = row - b * N;
     const int i = n / G, j = n - i * G;
@@ -307,15 +308,15 @@ __global__ __launch_bounds__(128) void camera_embed_kernel(const float* __restri
     const int t = threadIdx.x;
     T* cp = (T*)ctx16_ + (size_t)row * Kc + C;
     const float PI_F = 3.14159265358979323846f;
-    if (t < 99) {
+    if (t < E) {
         float v;
         if (t < 3) v = ray[t];
         else {
-            const int u = (t - 3) % 48, a = u / 16, kb = u % 16;
-            const float arg = PI_F * (ray[a] * freq[a * 16 + kb]);
-            v = (t - 3) < 48 ? sinf(arg) : cosf(arg);
+            const int u = (t - 3) % (3 * nbands), a = u / nbands, kb = u % nbands;
+            const float arg = PI_F * (ray[a] * freq[a * nbands + kb]);
+            v = (t - 3) < 3 * nbands ? sinf(arg) : cosf(arg);
         }
-        zK[(size_t)row * 99 + t] = v;
+        zK[(size_t)row * E + t] = v;
         cp[t] = (T)v;
     } else if (C + t < Kc) {
         cp[t] = (T)0.f;
@@ -338,9 +339,9 @@ __global__ __launch_bounds__(256) void hph_inputs_kernel(const float* __restrict
                                                          const float* __restrict__ cv_y, const float* __restrict__ init_tail,
                                                          int ntail, float* __restrict__ zc, float* __restrict__ token, int Ktok,
                                                          void* __restrict__ ctx16_, int Kc, int* __restrict__ det_row, int G,
-                                                         int C, const int* __restrict__ nvalid) {
+                                                         int C, const int* __restrict__ nvalid, int E) {
     typedef typename Op<DT>::T T;
-    const int p = blockIdx.x, Cc = C + 99;
+    const int p = blockIdx.x, Cc = C + E;        // E = camera embedding channels (99 for 16 bands)
     // fixed-capacity callers: rows >= *nvalid are padding (detection (0, 0, 0)); they are computed like persons and sliced off by the
     // host, but must not touch the context row of a cell nobody detected
     const bool real = nvalid == nullptr || p < *nvalid;
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(256) void hph_inputs_kernel(const float* __restrict
     for (int c = threadIdx.x; c < Ktok; c += 256) {
         float tv = 0.f;
         if (c < Cc) {
-            const float f = c < C ? feat32[row * C + c] : zK[row * 99 + (c - C)];
+            const float f = c < C ? feat32[row * C + c] : zK[row * E + (c - C)];
             if (c < C) zc[(size_t)p * C + c] = f;
             tv = f + (cq_x[(size_t)y * Cc + c] + cq_y[(size_t)x * Cc + c]);
             if (real) cp[c] = (T)(f + (cv_x[(size_t)y * Cc + c] + cv_y[(size_t)x * Cc + c]));
@@ -632,12 +633,12 @@ int mhmr_launch_person_groups(const int* counts, const int* det_b, int P, int B,
 }
 
 int mhmr_launch_camera_embed(const float* Kmat, const float* freq, int B, int G, int patch, float* zK, void* ctx16, int Kc,
-                             int C, int dtype, hipStream_t s) {
-    if (Kc - C > 128 || Kc - C < 99) return MHMR_ERR_BAD_SHAPE;
+                             int C, int dtype, int nbands, hipStream_t s) {
+    if (nbands < 1 || Kc - C > 128 || Kc - C < 3 + 6 * nbands) return MHMR_ERR_BAD_SHAPE;      // one thread per camera column: <= 20 bands
     if (dtype == MHMR_DT_F16)
-        hipLaunchKernelGGL((camera_embed_kernel<MHMR_DT_F16>), dim3(B * G * G), dim3(128), 0, s, Kmat, freq, G, patch, zK, ctx16, Kc, C);
+        hipLaunchKernelGGL((camera_embed_kernel<MHMR_DT_F16>), dim3(B * G * G), dim3(128), 0, s, Kmat, freq, G, patch, zK, ctx16, Kc, C, nbands);
     else
-        hipLaunchKernelGGL((camera_embed_kernel<MHMR_DT_BF16>), dim3(B * G * G), dim3(128), 0, s, Kmat, freq, G, patch, zK, ctx16, Kc, C);
+        hipLaunchKernelGGL((camera_embed_kernel<MHMR_DT_BF16>), dim3(B * G * G), dim3(128), 0, s, Kmat, freq, G, patch, zK, ctx16, Kc, C, nbands);
     MHMR_CHECK_LAUNCH();
     return 0;
 }
@@ -645,14 +646,15 @@ int mhmr_launch_camera_embed(const float* Kmat, const float* freq, int B, int G,
 int mhmr_launch_hph_inputs(const float* feat32, const float* zK, const int* det_b, const int* det_y, const int* det_x,
                            const float* cq_x, const float* cq_y, const float* cv_x, const float* cv_y, const float* init_tail,
                            int ntail, float* zc, float* token, int Ktok, void* ctx16, int Kc, int* det_row, int P, int G, int C,
-                           int dtype, const int* nvalid, hipStream_t s) {
+                           int dtype, const int* nvalid, int cam_dim, hipStream_t s) {
     if (P <= 0) return 0;
+    if (cam_dim < 3 || C + cam_dim > Kc) return MHMR_ERR_BAD_SHAPE;
     if (dtype == MHMR_DT_F16)
         hipLaunchKernelGGL((hph_inputs_kernel<MHMR_DT_F16>), dim3(P), dim3(256), 0, s, feat32, zK, det_b, det_y, det_x, cq_x, cq_y,
-                           cv_x, cv_y, init_tail, ntail, zc, token, Ktok, ctx16, Kc, det_row, G, C, nvalid);
+                           cv_x, cv_y, init_tail, ntail, zc, token, Ktok, ctx16, Kc, det_row, G, C, nvalid, cam_dim);
     else
         hipLaunchKernelGGL((hph_inputs_kernel<MHMR_DT_BF16>), dim3(P), dim3(256), 0, s, feat32, zK, det_b, det_y, det_x, cq_x, cq_y,
-                           cv_x, cv_y, init_tail, ntail, zc, token, Ktok, ctx16, Kc, det_row, G, C, nvalid);
+                           cv_x, cv_y, init_tail, ntail, zc, token, Ktok, ctx16, Kc, det_row, G, C, nvalid, cam_dim);
     MHMR_CHECK_LAUNCH();
     return 0;
 }

@@ -252,15 +252,16 @@ class Model(nn.Module):
         # (camera_embed_dim = 0, no `camera` module) -- and, as in the reference, such a model cannot run forward(): model.py:262 calls
         # embedd_camera() unconditionally, which needs self.camera (AttributeError there, AttributeError here).
         self.camera_embedding = camera_embedding
-        self.camera_embed_dim = 0
+        self.camera_embed_dim, self._camera_num_bands = 0, 16
         self._camera_max_resolution = camera_embedding_max_resolution
         if camera_embedding is not None:
             if camera_embedding != "geometric":
                 raise NotImplementedError("Only geometric camera embedding is implemented")
-            if camera_embedding_num_bands != 16:
-                raise NotImplementedError("the camera embedding kernel lays out 3 + 2*3*16 = 99 channels (camera_embedding_num_bands = 16, "
-                                          "what every released checkpoint uses); any camera_embedding_max_resolution is supported")
-            self.camera_embed_dim = 3 + 2 * 3 * camera_embedding_num_bands   # 99
+            if not 1 <= int(camera_embedding_num_bands) <= 20:
+                raise NotImplementedError("camera_embedding_num_bands must be 1 ... 20 (the camera embedding kernel writes the 3 + 6 bands "
+                                          "channels with one thread each, <= 128 columns behind the features); the released checkpoints use 16")
+            self._camera_num_bands = int(camera_embedding_num_bands)
+            self.camera_embed_dim = 3 + 2 * 3 * self._camera_num_bands       # 99 for 16 bands (FourierPositionEncoding.channels)
         self.mlp_classif = nn.Sequential(nn.Linear(self.embed_dim, self.embed_dim), nn.ReLU(), nn.Linear(self.embed_dim, 1))
         self.mlp_offset = nn.Sequential(nn.Linear(self.embed_dim, self.embed_dim), nn.ReLU(), nn.Linear(self.embed_dim, 2))
         self.nrot = 53
@@ -307,13 +308,15 @@ class Model(nn.Module):
             return t.data_ptr()
 
         # heads
-        Cc = C + 99
+        E, nbands = self.camera_embed_dim, self._camera_num_bands
+        Cc = C + E
         Kc = roundup(Cc, 64)
+        P["E"], P["nbands"] = E, nbands
         P["Cc"], P["Kc"] = Cc, Kc
         P["cls0_w"], P["cls0_b"] = op(self.mlp_classif[0].weight), f32(self.mlp_classif[0].bias)
         P["cls2_w"], P["cls2_b"] = f32(self.mlp_classif[2].weight.reshape(-1)), f32(self.mlp_classif[2].bias)
         # blocks/camera_embed.py:46: linspace(1, max_resolution / 2, num_bands) per ray component
-        P["freq"] = torch.stack([torch.linspace(1.0, self._camera_max_resolution / 2, 16) for _ in range(3)]).to(device).contiguous()
+        P["freq"] = torch.stack([torch.linspace(1.0, self._camera_max_resolution / 2, nbands) for _ in range(3)]).to(device).contiguous()
 
         # HPH
         hp = self.x_attention_head
@@ -373,7 +376,7 @@ class Model(nn.Module):
     def _workspace(self, P, B):
         def extra(P, B, z):
             Mp = roundup(B * P["N"], 128)
-            return dict(ctx16=z(Mp, P["Kc"]), zK=z(B * P["N"], 99, dtype=torch.float32), scores=z(B * P["N"], dtype=torch.float32),
+            return dict(ctx16=z(Mp, P["Kc"]), zK=z(B * P["N"], P["E"], dtype=torch.float32), scores=z(B * P["N"], dtype=torch.float32),
                         counts=z(B, dtype=torch.int32), kv=z(Mp, P["hph"]["n_kv"], dtype=torch.float32),
                         hid_cls=z(Mp, P["C"]))
         return self._ws.get(P, B, extra, self._nsplit(B))
@@ -464,7 +467,7 @@ class Model(nn.Module):
         self._run_backbone(P, ws, x)
         # 2. camera embedding (model.py:262) -> zK + context operand columns C..C+98
         _lib.check(L.mhmr_camera_embed(K.data_ptr(), P["freq"].data_ptr(), B, G, PATCH, ws["zK"].data_ptr(), ws["ctx16"].data_ptr(), Kc,
-                                       Cdim, dt, stream), "mhmr_camera_embed")
+                                       Cdim, dt, P["nbands"], stream), "mhmr_camera_embed")
         # 3. detection scores (model.py:135): mlp_classif.0 + ReLU on MFMA, then the C->1 read-out + clamped sigmoid
         _lib.check(L.mhmr_gemm16(ws["ctx16"].data_ptr(), Kc, P["cls0_w"].data_ptr(), Cdim, Mp, Cdim, Cdim, P["cls0_b"].data_ptr(), None,
                                  ws["hid_cls"].data_ptr(), Cdim, None, 0, 128, 1, Mp, _lib.EPI_OP16_RELU, dt, stream), "mhmr_gemm16(classif)")
@@ -581,6 +584,7 @@ class Model(nn.Module):
             setattr(d, n, t.data_ptr())
         d.kv = ws["kv"].data_ptr()
         d.nvalid = info.data_ptr() if info is not None else None
+        d.cam_dim = P["E"]
         if o is None:
             o = self._alloc_outputs(P, Pn, dev)
         offset, loc, rotmat, rotvec, shape, expression = o["offset"], o["loc"], o["rotmat"], o["rotvec"], o["shape"], o["expression"]

@@ -50,14 +50,14 @@ def fourier_features(pos, num_bands=16, max_resolution=64):
     return torch.cat([pos, feat], dim=-1)
 
 
-def embedd_camera(K, G):
+def embedd_camera(K, G, num_bands=16, max_resolution=64):
     """model.py:160-187.  NB the ROW index is fed as pixel-x and the COLUMN index as pixel-y (model.py:164-177)."""
     bs = K.shape[0]
     pts = torch.stack([torch.arange(G).reshape(-1, 1).repeat(1, G), torch.arange(G).reshape(1, -1).repeat(G, 1)], -1).float()
     pts = pts * PATCH + PATCH // 2
     pts = pts.reshape(1, -1, 2).repeat(bs, 1, 1)
     rays = inverse_perspective_projection(pts, K, torch.ones(bs, pts.shape[1], 1))
-    return fourier_features(rays).reshape(bs, G, G, 99)
+    return fourier_features(rays, num_bands, max_resolution).reshape(bs, G, G, 3 + 6 * num_bands)
 
 
 # ---------------------------------------------------------------- model.py helpers
@@ -219,7 +219,9 @@ class OracleModel:
     """Functional CPU fp32 Multi-HMR.  ``forward`` == reference Model.forward (model.py:205-349)."""
 
     def __init__(self, state_dict: dict, smplx_data: dict, backbone="dinov2_vitl14", img_size=896, xat_depth=2,
-                 xat_num_heads=8, num_betas=10, depth_override=None, nearness=True):
+                 xat_num_heads=8, num_betas=10, depth_override=None, nearness=True, camera_embedding_num_bands=16,
+                 camera_embedding_max_resolution=64):
+        self.num_bands, self.max_resolution = camera_embedding_num_bands, camera_embedding_max_resolution      # model.py:39-40
         self.sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
         self.img_size, self.depth, self.heads, self.nearness = img_size, xat_depth, xat_num_heads, nearness
         self.vit = dinov2_ref.build(backbone, depth_override)
@@ -246,7 +248,7 @@ class OracleModel:
         z_central = zmap[idx[0], :, idx[1], idx[2]]                                # :255
         offset = mlp2(sd, "mlp_offset", z_central)                                 # :258
         K_det = K[idx[0]]
-        z_K = embedd_camera(K, G)                                                  # :262
+        z_K = embedd_camera(K, G, self.num_bands, self.max_resolution)             # :262
         z_central = torch.cat([z_central, z_K[idx[0], idx[1], idx[2]]], 1)         # :263-265
         z_all = torch.cat([zmap, z_K.permute(0, 3, 1, 2)], 1)                      # :266-268
         loc = (torch.stack([idx[2], idx[1]]).permute(1, 0) + 0.5 + offset) * PATCH  # :272-275

@@ -113,7 +113,7 @@ def _trunc_normal(gen, shape, std=0.02):
 def make_state_dict(backbone: str = "dinov2_vitl14", img_size: int = 896, xat_depth: int = 2,
                     xat_num_heads: int = 8, num_betas: int = 10, seed: int = 0,
                     depth_override: int | None = None, mean_params: dict | None = None,
-                    layerscale: float = 1.0) -> dict:
+                    layerscale: float = 1.0, camera_num_bands: int = 16) -> dict:
     """Seeded random ``model_state_dict`` with the reference's key names and shapes.
 
     Initialisation follows the reference constructors (DINOv2: trunc-normal(0.02) linears, zero bias,
@@ -165,7 +165,7 @@ def make_state_dict(backbone: str = "dinov2_vitl14", img_size: int = 896, xat_de
     lin("mlp_offset.2", 2, C, std=0.2 / math.sqrt(C))
 
     G = img_size // 14
-    Cc = C + 99
+    Cc = C + 3 + 6 * camera_num_bands            # 99 camera channels for the released checkpoints' 16 bands
     h = "x_attention_head."
     for n in ("cross_queries_x", "cross_queries_y", "cross_values_x", "cross_values_y"):
         sd[h + n] = 0.2 * torch.empty(G, Cc).normal_(0, 1, generator=g)

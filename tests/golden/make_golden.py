@@ -38,6 +38,9 @@ CASES = {
     "vitl_672_full": dict(backbone="dinov2_vitl14", img_size=672, depth_override=None, batch=1, persons=[8], seed=22, vstride=4),
     "vitl_896_full": dict(backbone="dinov2_vitl14", img_size=896, depth_override=None, batch=1, persons=[8], seed=23, vstride=4),
     "vitl_1288_full": dict(backbone="dinov2_vitl14", img_size=1288, depth_override=None, batch=1, persons=[20], seed=24, vstride=8),
+    # constructor arguments off their defaults (model.py:39-40): 8 frequency bands up to resolution 32 -> 51 camera channels
+    "vits_224_bands8": dict(backbone="dinov2_vits14", img_size=224, depth_override=2, batch=2, persons=[2, 3], seed=41,
+                            model_kwargs=dict(camera_embedding_num_bands=8, camera_embedding_max_resolution=32)),
     # hostile weight statistics (synthetic.make_hostile): what a trained checkpoint may look like and the N(1, 0.1) weights do not --
     # LayerScale over three orders of magnitude, LayerNorm weights with x10 ... x30 channels, large LayerNorm / qkv biases ("weights");
     # token rows whose mean is ~2 standard deviations from zero through the whole depth ("mean").  Full-depth ViT-L at 672^2.
@@ -73,7 +76,8 @@ def case_inputs(cfg):
 
 
 def case_state_dict(cfg):
-    sd = synthetic.make_state_dict(cfg["backbone"], cfg["img_size"], seed=cfg["seed"], depth_override=cfg["depth_override"])
+    sd = synthetic.make_state_dict(cfg["backbone"], cfg["img_size"], seed=cfg["seed"], depth_override=cfg["depth_override"],
+                                   camera_num_bands=cfg.get("model_kwargs", {}).get("camera_embedding_num_bands", 16))
     if cfg.get("hostile"):
         synthetic.make_hostile(sd, cfg["hostile"], seed=cfg["seed"])
     return sd
@@ -90,7 +94,7 @@ def main():
         x, K, idx = case_inputs(cfg)
         with ref_shim.reference_modules(smplx_data, mean_params, cfg["depth_override"]) as ref:
             torch.manual_seed(0)
-            model = ref.Model(backbone=cfg["backbone"], img_size=cfg["img_size"])
+            model = ref.Model(backbone=cfg["backbone"], img_size=cfg["img_size"], **cfg.get("model_kwargs", {}))
             missing, unexpected = model.load_state_dict(sd, strict=False)
             missing = [m for m in missing if "smpl_layer" not in m]
             assert not missing and not unexpected, (missing, unexpected)

@@ -563,22 +563,26 @@ def test_nms_threshold_compaction(L, k):
     assert torch.equal(dsc.cpu(), heat[ref_idx[0], ref_idx[3], ref_idx[1], ref_idx[2]])
 
 
-def test_camera_embed(L):
+@pytest.mark.parametrize("nbands,maxres", [(16, 64), (8, 64), (20, 32), (1, 64)])      # 16 / 64: the released checkpoints (model.py:39-40)
+def test_camera_embed(L, nbands, maxres):
     from oracle.multihmr_ref import embedd_camera
     B, G, C, Kc = 2, 16, 384, 512
+    E = 3 + 6 * nbands
     K = synthetic.get_camera_K(G * 14, B)
     K[1, 0, 0] *= 1.1
     K[1, 0, 2] += 5
     K[1, 0, 1] = 0.3       # a skewed camera exercises the general 3x3 inverse
-    freq = torch.stack([torch.linspace(1.0, 32.0, 16) for _ in range(3)]).to(dev()).contiguous()
-    zK = torch.zeros(B * G * G, 99, device=dev())
+    freq = torch.stack([torch.linspace(1.0, maxres / 2, nbands) for _ in range(3)]).to(dev()).contiguous()
+    zK = torch.zeros(B * G * G, E, device=dev())
     ctx = torch.full((B * G * G, Kc), 5.0, dtype=torch.float16, device=dev())
     Kd = K.to(dev()).contiguous()
-    _lib.check(L.mhmr_camera_embed(Kd.data_ptr(), freq.data_ptr(), B, G, 14, zK.data_ptr(), ctx.data_ptr(), Kc, C, _lib.DT_F16, stream()), "cam")
-    ref = embedd_camera(K, G).reshape(B * G * G, 99)
+    _lib.check(L.mhmr_camera_embed(Kd.data_ptr(), freq.data_ptr(), B, G, 14, zK.data_ptr(), ctx.data_ptr(), Kc, C, _lib.DT_F16, nbands, stream()), "cam")
+    ref = embedd_camera(K, G, nbands, maxres).reshape(B * G * G, E)
     assert float((zK.cpu() - ref).abs().max()) < 2e-4     # sin/cos of arguments up to ~60 rad in fp32
-    assert torch.all(ctx[:, :C] == 5.0) and torch.all(ctx[:, C + 99:] == 0.0)
-    assert float((ctx[:, C:C + 99].float().cpu() - ref).abs().max()) < 2e-3
+    assert torch.all(ctx[:, :C] == 5.0) and torch.all(ctx[:, C + E:] == 0.0)
+    assert float((ctx[:, C:C + E].float().cpu() - ref).abs().max()) < 2e-3
+    # more bands than one thread per camera column can write behind the features: refused, not truncated
+    assert L.mhmr_camera_embed(Kd.data_ptr(), freq.data_ptr(), B, G, 14, zK.data_ptr(), ctx.data_ptr(), Kc, C, _lib.DT_F16, 22, stream()) == -2
 
 
 # ------------------------------------------------------------------------------------------------------ LBS

@@ -27,13 +27,13 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 def build(cfg, smplx_data, mean_params, precision, sd=None):
     sd = make_golden.case_state_dict(cfg) if sd is None else sd
     m = Model(backbone=cfg["backbone"], img_size=cfg["img_size"], smplx_data=smplx_data, mean_params=mean_params,
-              backbone_depth=cfg["depth_override"], precision=precision)
+              backbone_depth=cfg["depth_override"], precision=precision, **cfg.get("model_kwargs", {}))
     missing, unexpected = m.load_state_dict(sd, strict=True)
     return m.to("cuda:0").eval()
 
 
 @pytest.mark.parametrize("precision", ["f16", "bf16"])
-@pytest.mark.parametrize("name", ["vits_224_train", "vitb_224_train", "vitl_224_train"])
+@pytest.mark.parametrize("name", ["vits_224_train", "vitb_224_train", "vitl_224_train", "vits_224_bands8"])   # bands8: 51 camera channels
 def test_training_mode_matches_reference_golden(name, precision, smplx_data, mean_params):
     cfg = make_golden.CASES[name]
     gold = np.load(os.path.join(GOLD, name + ".npz"))
