@@ -361,14 +361,20 @@ class Model(nn.Module):
         return P
 
     def _nsplit(self, B):
-        """Image blocks of the batch that run the backbone on streams of their own (MHMR_SPLIT / ``split=``; default 2 for even
-        batches of >= 8 images).  Images never interact inside the backbone, so the blocks are independent launches sequences: the
-        persistent GEMM / attention launches of one block start on the CUs that the tail of the other block's launch leaves idle
-        (launch ramps and tails are ~3 % of a single-stream forward).  Results do not depend on it (every kernel
-        is batch-invariant: tests/test_gpu_fullsize.py)."""
+        """Image blocks of the batch that run the backbone on streams of their own (``split=`` / MHMR_SPLIT; 0 or unset = automatic).
+        Images never interact inside the backbone, so the blocks are independent launch sequences: the persistent GEMM / attention
+        launches of one block start on the CUs that the tail of the other block's launch leaves idle.  That pays when a launch is only
+        a few rounds of 256 tiles long -- measured (profiles/r04_split_colgroup_ab.txt, r04_session_c_*.txt): config 5 (1288^2, 8 images:
+        4.2 rounds in the N = 1024 linears) +4.2 %, config 2 (ViT-S 672^2, 16 images) +5.2 %, config 3 +2 %; the headline (896^2, 32
+        images: 8 exact rounds) +0.3 %, where it is left off so that every kernel has the chip to itself (per-kernel hipEvent / rocprofv3
+        durations then mean what they say).  Automatic rule: two blocks when the batch is even, >= 8 images, and the narrowest block
+        linear is under six rounds.  Results do not depend on it (every kernel is batch-invariant: tests/test_gpu_fullsize.py,
+        test_backbone_image_blocks_on_side_streams_change_nothing)."""
         n = self.split if self.split is not None else int(os.environ.get("MHMR_SPLIT", "0"))
         if n <= 0:
-            n = 2 if (B >= 8 and B % 2 == 0) else 1
+            T = (self.img_size // PATCH) ** 2 + 1
+            rounds = (B * roundup(T, 64) / 256.0) * max(self.embed_dim // 256, 1) / 256.0
+            n = 2 if (B >= 8 and B % 2 == 0 and rounds < 6.0) else 1
         while n > 1 and (B % n or B // n < 1):
             n -= 1
         return n

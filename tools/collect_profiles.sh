@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh rNN   ->  gpurun_out/rNN/{kernel_stats.txt, pmc.json, ...}; copy the summaries into profiles/.
 # Counters are collected in their own runs (one --pmc set per run, --kernel-trace only beside them).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT/pmc/lbs $OUT/trace
 cd /tmp && export TMPDIR=/tmp
