@@ -413,11 +413,17 @@ __global__ __launch_bounds__(64) void hph_self_attn_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------------------
 constexpr int CA_WAVES = 8;
 __global__ __launch_bounds__(64 * CA_WAVES) void hph_cross_attn_kernel(const float* __restrict__ q, const float* __restrict__ kv,
-                                                            const int* __restrict__ chunks, float* __restrict__ out, int inner,
+                                                            const int* __restrict__ chunks, int ncap, float* __restrict__ out, int inner,
                                                             int N, float scale) {
-    const int ch = blockIdx.x, h = blockIdx.y;
+    // 1-D grid of ncap x heads workgroups over a work list of ncap entries whose tail may be padding (count 0: person_groups_kernel
+    // pads up to the launch's upper bound).  The real work is the FIRST nc x heads workgroups: the dispatcher hands out workgroups in
+    // index order, two per CU -- with the padding interleaved (a 2-D grid, real chunks 0..31 of 64 in every row) half of the CUs
+    // received two real workgroups and the other half two that return at once: 221 instead of 118 us per layer.
+    const int nc = __syncthreads_count(threadIdx.x < ncap && chunks[3 * threadIdx.x + 2] > 0);      // (ncap <= 512: the launcher)
+    const int heads = inner >> 5;
+    if ((int)blockIdx.x >= nc * heads) return;
+    const int ch = blockIdx.x % nc, h = blockIdx.x / nc;
     const int b = chunks[3 * ch], q0 = chunks[3 * ch + 1], nq = chunks[3 * ch + 2];
-    if (nq <= 0) return;          // (person_groups_kernel pads the work list up to the launch's upper bound; uniform per workgroup)
     __shared__ float part[CA_WAVES][8][34];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, qi = lane & 7, sl = lane >> 3;
     const bool active = qi < nq;
@@ -672,8 +678,12 @@ int mhmr_launch_hph_self_attn(const float* qkv, const int* gstart, float* out, i
 int mhmr_launch_hph_cross_attn(const float* q, const float* kv, const int* chunks, int nchunks, float* out, int heads, int N,
                                hipStream_t s) {
     if (nchunks <= 0) return 0;
-    hipLaunchKernelGGL(hph_cross_attn_kernel, dim3(nchunks, heads), dim3(64 * CA_WAVES), 0, s, q, kv, chunks, out, heads * 32, N,
-                       0.17677669529663688110f);
+    // work lists longer than one workgroup can count (512 entries = 4096 persons in one batch) take one launch per 512 entries
+    for (int c0 = 0; c0 < nchunks; c0 += 64 * CA_WAVES) {
+        const int n = nchunks - c0 < 64 * CA_WAVES ? nchunks - c0 : 64 * CA_WAVES;
+        hipLaunchKernelGGL(hph_cross_attn_kernel, dim3(n * heads), dim3(64 * CA_WAVES), 0, s, q, kv, chunks + 3 * c0, n, out, heads * 32, N,
+                           0.17677669529663688110f);
+    }
     MHMR_CHECK_LAUNCH();
     return 0;
 }

@@ -640,10 +640,17 @@ extern "C" int mhmr_lbs_forward(const mhmr_lbs_consts* c, const float* rotvec, c
         return MHMR_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int Pp = (P + 15) / 16 * 16;
-    {   // 126 KB of dynamic LDS: above the default per-kernel limit.  The attribute is per DEVICE: set it on every call (cheap) rather
-        // than remember a process-wide flag that is wrong for the second GPU of a process
-        hipError_t e = hipFuncSetAttribute((const void*)lbs_vertex_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LBS_LDS);
-        if (e != hipSuccess) return (int)e;
+    {   // 141 KB of dynamic LDS: above the default per-kernel limit.  The attribute is per DEVICE (DeviceOnce, mhmr_internal.h: one
+        // driver call per device and process, not one per forward)
+        static DeviceOnce once;
+        int dev = 0;
+        const int need = once.need(&dev);
+        if (need == -2) return MHMR_ERR_BAD_ARG;
+        if (need >= 0) {
+            hipError_t e = hipFuncSetAttribute((const void*)lbs_vertex_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LBS_LDS);
+            if (e != hipSuccess) return (int)e;
+            once.mark(dev);
+        }
     }
     hipLaunchKernelGGL(lbs_pose_kernel, dim3(Pp), dim3(64), 0, s, *c, rotvec, betas, expr, loc, dist, Kmat, det_b, P, Pp,
                        (_Float16*)ws_F, (_Float16*)ws_A, ws_xf, j3d, j2d, transl);
