@@ -411,8 +411,9 @@ class Model(nn.Module):
             _lib.check(L.mhmr_vit_forward(C.byref(part["desc"]), x.data_ptr() + i0 * img_elems * 4, ws["feat32"].data_ptr() + i0 * N * Cd * 4,
                                           ws["ctx16"].data_ptr() + i0 * N * Kc * esz_ctx, Kc, stream.cuda_stream), "mhmr_vit_forward")
 
-        if len(parts) == 1:
-            launch(parts[0], main)
+        if len(parts) == 1 or os.environ.get("MHMR_SPLIT_SEQ"):        # (MHMR_SPLIT_SEQ: the blocks one after the other on one stream, A/B only)
+            for part in parts:
+                launch(part, main)
             return
         streams, fork, joins = self._side_streams(dev, len(parts))
         fork.record(main)
