@@ -181,7 +181,8 @@ int mhmr_detect_write_cap(const float* scores, int B, int G, int nms_kernel, flo
  * [ngroups_cap + 1], chunks [3 * nchunks_cap] as mhmr_hph_forward reads them (unused tail entries = empty groups / count-0 items) and
  * info[4] = {persons kept = min(total, cap), groups, chunks, total}.  counts [B] from mhmr_detect_count, or NULL: the counts are the
  * histogram of det_b[0..P) (training hook: the caller's idx, sorted by image).  Sufficient bounds: ngroups_cap = min(B, cap),
- * nchunks_cap = cap / 8 + min(B, cap).  B <= 8192. */
+ * nchunks_cap = cap / 8 + min(B, cap).  One workgroup builds the tables in LDS: (2 B + ngroups_cap + 1 + 3 nchunks_cap) ints must fit
+ * 60 KB (B <= 8192 and, e.g., 2048 images with 16 persons each), MHMR_ERR_BAD_SHAPE otherwise. */
 int mhmr_person_groups(const int* counts, const int* det_b, int P, int B, int cap, int* base, int* gstart, int ngroups_cap,
                        int* chunks, int nchunks_cap, int* info, void* stream);
 

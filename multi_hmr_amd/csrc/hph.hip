@@ -249,28 +249,38 @@ __global__ __launch_bounds__(256) void person_groups_kernel(const int* __restric
         }
         __syncthreads();
     }
+    // the serial part runs on one lane against LDS (a chain of dependent GLOBAL stores made this 10 us); everybody writes the tables out
+    int* sbase = cnt + B;                 // [B]
+    int* sg = sbase + B;                  // [ngcap + 1]
+    int* sc = sg + ngcap + 1;             // [3 * nccap]
+    __shared__ int sinfo[4];
     if (t == 0) {
         int start = 0, total = 0, ng = 0, nc = 0;
-        gstart[0] = 0;
+        sg[0] = 0;
         for (int b = 0; b < B; ++b) {
             const int c = cnt[b];
-            if (base) base[b] = total;
+            sbase[b] = total;
             total += c;
             const int kept = min(c, max(cap - start, 0));
             if (kept > 0) {
                 for (int q0 = 0; q0 < kept; q0 += 8) {
-                    if (nc < nccap) { chunks[3 * nc] = b; chunks[3 * nc + 1] = start + q0; chunks[3 * nc + 2] = min(8, kept - q0); }
+                    if (nc < nccap) { sc[3 * nc] = b; sc[3 * nc + 1] = start + q0; sc[3 * nc + 2] = min(8, kept - q0); }
                     ++nc;
                 }
                 start += kept;
-                if (ng < ngcap) gstart[ng + 1] = start;
+                if (ng < ngcap) sg[ng + 1] = start;
                 ++ng;
             }
         }
-        for (int g = min(ng, ngcap); g < ngcap; ++g) gstart[g + 1] = start;
-        for (int c = min(nc, nccap); c < nccap; ++c) { chunks[3 * c] = 0; chunks[3 * c + 1] = 0; chunks[3 * c + 2] = 0; }
-        info[0] = start; info[1] = min(ng, ngcap); info[2] = min(nc, nccap); info[3] = total;
+        for (int g = min(ng, ngcap); g < ngcap; ++g) sg[g + 1] = start;
+        for (int c = min(nc, nccap); c < nccap; ++c) { sc[3 * c] = 0; sc[3 * c + 1] = 0; sc[3 * c + 2] = 0; }
+        sinfo[0] = start; sinfo[1] = min(ng, ngcap); sinfo[2] = min(nc, nccap); sinfo[3] = total;
     }
+    __syncthreads();
+    if (base) for (int b = t; b < B; b += 256) base[b] = sbase[b];
+    for (int g = t; g <= ngcap; g += 256) gstart[g] = sg[g];
+    for (int c = t; c < 3 * nccap; c += 256) chunks[c] = sc[c];
+    if (t < 4) info[t] = sinfo[t];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -632,8 +642,9 @@ int mhmr_launch_person_groups(const int* counts, const int* det_b, int P, int B,
                               int nccap, int* info, hipStream_t s) {
     if (B <= 0 || B > 8192 || P < 0 || cap < 0 || ngcap < 0 || nccap < 0 || !gstart || !info || (nccap > 0 && !chunks)) return MHMR_ERR_BAD_ARG;
     if (!counts && P > 0 && !det_b) return MHMR_ERR_BAD_ARG;
-    hipLaunchKernelGGL(person_groups_kernel, dim3(1), dim3(256), (size_t)B * sizeof(int), s, counts, det_b, P, B, cap, base, gstart, ngcap,
-                       chunks, nccap, info);
+    const size_t lds = ((size_t)2 * B + (size_t)ngcap + 1 + (size_t)3 * nccap) * sizeof(int);
+    if (lds > 60 * 1024) return MHMR_ERR_BAD_SHAPE;          // (B = 8192 with the sufficient bounds is 160 KB: far beyond any batch)
+    hipLaunchKernelGGL(person_groups_kernel, dim3(1), dim3(256), lds, s, counts, det_b, P, B, cap, base, gstart, ngcap, chunks, nccap, info);
     MHMR_CHECK_LAUNCH();
     return 0;
 }
