@@ -337,3 +337,48 @@ def test_backbone_image_blocks_on_side_streams_change_nothing(name, smplx_data, 
         for k in ("scores", "v3d", "rotmat", "shape", "expression", "transl", "j2d"):
             assert torch.equal(outs[0][k], one[k]) and torch.equal(outs[4][k], one[k]), (split, k)
         assert not torch.equal(outs[1]["v3d"], one["v3d"])
+
+
+def test_two_host_threads_with_split_backbones_soak(smplx_data, mean_params):
+    """The two-thread / two-stream gate at full depth with 8-image batches whose backbone runs as two image blocks on side streams of
+    each model (2 threads x 2 streams each, interleaving GEMMs, attention, class-row kernels and folded LayerNorms of two different
+    weight sets on one GPU): 40 forwards per thread, every one bit-equal to the serial run.  This is the configuration in which the
+    round-3 packed-fp32 failure (csrc/mhmr_common.h; root cause still open) showed within a few dozen forwards of an SLP build."""
+    import threading
+    cfg = dict(make_golden.CASES["vitl_224_train"], batch=8, persons=[1, 0, 2, 1, 0, 1, 3, 0])
+    x, K, idx = make_golden.case_inputs(cfg)
+    xc, Kc, ic = x.cuda(), K.cuda(), tuple(i.cuda() for i in idx)
+    sds = [make_golden.case_state_dict(cfg), synthetic.make_state_dict(cfg["backbone"], cfg["img_size"], seed=91, depth_override=cfg["depth_override"])]
+
+    def mk(sd):
+        m = Model(backbone=cfg["backbone"], img_size=cfg["img_size"], smplx_data=smplx_data, mean_params=mean_params, precision="f16", split=2)
+        m.load_state_dict(sd, strict=True)
+        return m.to("cuda:0").eval()
+    models = [mk(sd) for sd in sds]
+    assert models[0]._nsplit(8) == 2
+    serial = [m(xc, idx=ic, K=Kc, is_training=True) for m in models]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in models]
+    bad, errors = [0, 0], []
+
+    def worker(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                for _ in range(40):
+                    out = models[i](xc, idx=ic, K=Kc, is_training=True)
+                    if not all(torch.equal(out[k], serial[i][k]) for k in ("scores", "v3d", "rotmat", "shape", "expression", "transl")):
+                        bad[i] += 1
+            streams[i].synchronize()
+        except Exception as e:          # noqa: BLE001
+            errors.append(e)
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    assert bad == [0, 0], bad
+    assert not torch.equal(serial[0]["v3d"], serial[1]["v3d"])
