@@ -35,6 +35,17 @@ __device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c) {
 #else
 __device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 #endif
+#ifdef MFMA32
+// Round-4 question (needs V3 + ASM_MFMA): does the MFMA SHAPE move the power-limited rate?  v_mfma_f32_32x32x16 does the work of two
+// 16x16x32 with the same two operand fragments' worth of register reads (16 instead of 8 multiply-adds per operand element read).  This
+// variant issues HALF as many MFMAs of the 32x32x16 shape on the SAME fragment registers, fed by the same LDS reads and copies, with the
+// same 256 accumulator registers -- the products are NOT the GEMM (the fragment layouts of the two shapes differ; `max err` is meaningless
+// here), but operand bits, instruction counts, bytes and flops are those of a real 32x32x16 main loop.
+__device__ __forceinline__ f32x16 mfma32(V8 a, V8 b, f32x16 c) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    return c;
+}
+#endif
 
 // stamps: [block][tile][2] wall clock at the start / end of the tile's k loop (wave 0)
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4w_kernel(const T* __restrict__ A, const T* __restrict__ W,
@@ -71,7 +82,26 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     for (int ks = 0; ks < 2; ++ks) co[ks] = ((4 * ks + g4) ^ fsw) * 16;
     const int p_off = wp * HT + l15 * 128, q_off = (2 + wq) * HT + l15 * 128;
 
+#ifdef MFMA32
+    f32x16 acc32[4][4];
+#define ACC_ZERO()                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)            \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f
+    // group i of a k step: fragment P_i against the four Q fragments of its parity: 4 MFMAs (the 16x16x32 form: 8)
+#define MM_GROUP(set, i)                                         \
+    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {           \
+        const int j = 2 * jj + ((i) & 1);                        \
+        acc32[(i) >> 1][jj] = mfma32(PF[set][i], QF[set][j], acc32[(i) >> 1][jj]); \
+    }
+#else
     f32x4 acc[8][8];
+#define ACC_ZERO()                                               \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}
+#define MM_GROUP(set, i)                                         \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[i][j] = mfma(PF[set][i], QF[set][j], acc[i][j])
+#endif
     V8 PF[2][8], QF[2][8];             // [k step parity][16-row sub-tile]
     auto rd = [&](int set, int buf, int ks) {
 #pragma unroll
@@ -83,9 +113,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     auto mm = [&](int set) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = mfma(PF[set][i], QF[set][j], acc[i][j]);
+        for (int i = 0; i < 8; ++i) { MM_GROUP(set, i); }
         __builtin_amdgcn_s_setprio(0);
     };
 #define SYNC()                       \
@@ -114,10 +142,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         const bool has_next = r + 1 < nmine;
         if (has_next) bases(tile_of(r + 1), pn, qn, n0n, m0n);
         else { pn = pb; qn = qb; n0n = n0; m0n = m0; }
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        ACC_ZERO();
 #ifdef ASM_MFMA
         asm volatile("s_nop 7" ::: "memory");
 #endif
@@ -138,8 +163,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             const char* nxt = smem + (buf ^ 1) * BUF;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = mfma(PF[0][i], QF[0][j], acc[i][j]);
+                MM_GROUP(0, i);
                 __builtin_amdgcn_sched_barrier(0);
                 if (i < 2) {
 #pragma unroll
@@ -165,8 +189,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = mfma(PF[1][i], QF[1][j], acc[i][j]);
+                MM_GROUP(1, i);
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef EARLY_DMA
 #pragma unroll
@@ -241,6 +264,17 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         asm volatile("s_nop 15\n s_nop 15" ::: "memory");      // (the compiler does not see the MFMAs inside the asm: the accumulator reads below need their wait states)
 #endif
         // ---- plain epilogue: lane holds C[m = m0 + 128 wq + 16 j + l15][n = n0 + 128 wp + 16 i + 4 g4 + 0..3] ----
+#ifdef MFMA32
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {      // (same stores; which accumulator element lands where does not matter for this variant)
+                V4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (T)acc32[i >> 1][j >> 1][4 * (2 * (i & 1) + (j & 1)) + e];
+                *(V4*)(C + (size_t)(m0 + 128 * wq + 16 * j + l15) * N + n0 + 128 * wp + 16 * i + 4 * g4) = o;
+            }
+#else
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -250,6 +284,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 for (int e = 0; e < 4; ++e) o[e] = (T)acc[i][j][e];
                 *(V4*)(C + (size_t)(m0 + 128 * wq + 16 * j + l15) * N + n0 + 128 * wp + 16 * i + 4 * g4) = o;
             }
+#endif
         pb = pn; qb = qn; n0 = n0n; m0 = m0n;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
