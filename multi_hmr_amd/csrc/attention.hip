@@ -657,6 +657,279 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(const void* __restrict__
     finish_block(Bq, 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The MODE 3 arithmetic on v_mfma_f32_16x16x32 (round 4, variant 6).  tools/ubench/gemm4w.hip -DMFMA32 showed that the 32x32x16 shape
+// costs 5-8 % more power per flop than 16x16x32 (profiles/r04_mfma_shape_prototype.txt: slower on random data, equal on zeros), and this
+// kernel runs at the lowest clock of the forward (1.6 GHz).  Same workgroup (4 waves x 32 queries, 64-key tiles, 2-slot K / V^T ring,
+// MODE 3 level + flags, the same V^T layout), other fragment geometry:
+//   a wave's 32 queries are two 16-query blocks qb; lane (j = lane & 15, g = lane >> 4) holds, per block, query 16 qb + j and FOUR
+//   lane-groups' worth of keys: of every 32-key half m of the tile the score blocks X (keys 0-3 | 4-7 | 16-19 | 20-23 of the half, one
+//   quad per g) and Y (the same + 8), so that [X quad | Y quad] of lane (j, g) are the eight keys whose V^T values sit in ONE 16-byte
+//   chunk of the key-permuted V^T row: P feeds the PV product in place, as in the 32x32 form.  S^T = K . Q^T: 16 MFMAs (2 halves x X / Y
+//   x 2 query blocks x 2 k steps), O^T += V^T . P^T: 16 MFMAs (2 halves x 4 d blocks x 2 query blocks); 8 + 8 ds_read_b128 per tile.
+//   The K tile's rows are read in the order 0-7, 16-23 (X) / 8-15, 24-31 (Y): its LDS swizzle is ((row >> 1) & 3) | ((row >> 4) & 1) << 2
+//   (applied on the copy's source address), which keeps those sixteen rows on sixteen different 16-byte slots; V^T keeps (row >> 1) & 7.
+//   A query's keys are spread over the four lanes j, j + 16, j + 32, j + 48: the row maximum of tile 0, the row sums at the end and the
+//   lone last key's dot product close over them with two lane exchanges each.
+template <int DT>
+__global__ __launch_bounds__(256, 4) void attn16_kernel(const void* __restrict__ qk_, const void* __restrict__ vt_, void* __restrict__ out_,
+                                                        int T, int Tp, int C, int H, int nqt, float limit, int* __restrict__ flags) {
+    typedef typename Op<DT>::T Tt;
+    typedef typename Op<DT>::V8 V8;
+    typedef typename Op<DT>::V4 V4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | Vt tile] + one 64-float strip per wave
+    constexpr int QB = 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j15 = lane & 15, g = lane >> 4;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = bid % nqt, bh = bid / nqt;
+    const int b = bh / H, h = bh - b * H;
+    if (qt * QB >= T) {
+        if (lane == 0) flags[4 * bid + w] = 0;
+        return;
+    }
+    const Tt* qk = (const Tt*)qk_;
+    const Tt* vt = (const Tt*)vt_;
+    const int ldq = 2 * C;
+    const size_t row0 = (size_t)b * Tp;
+    const bool active = qt * QB + 32 * w < T;
+    const bool in_buf = qt * QB + 32 * w < Tp;
+    // Q fragments (second operand): lane (j, g) holds Q[16 qb + j][32 ks + 8 g + 0..7]
+    V8 qf[2][2] = {};
+    if (in_buf) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const Tt* qp = qk + (row0 + qt * QB + 32 * w + 16 * qb + j15) * ldq + h * 64 + 8 * g;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) qf[qb][ks] = *(const V8*)(qp + 32 * ks);
+        }
+    }
+    // staging: one copy per thread moves 32 tile rows; K with this kernel's swizzle, V^T with the common one
+    const int srow = tid >> 3;
+    const int kchunk = (tid & 7) ^ (((srow >> 1) & 3) | (((srow >> 4) & 1) << 2));
+    const int vchunk = (tid & 7) ^ ((srow >> 1) & 7);
+    const Tt* k_src = qk + (row0 + srow) * ldq + C + h * 64 + kchunk * 8;
+    const Tt* v_src = vt + ((size_t)(b * H + h) * 64 + srow) * Tp + vchunk * 8;
+    auto stage = [&](int jt, int buf) {
+        char* sk = smem + buf * (2 * KV_TILE_BYTES) + w * 1024;
+        char* sv = sk + KV_TILE_BYTES;
+        const Tt* kp = k_src + (size_t)jt * KB * ldq;
+        const Tt* vp = v_src + jt * KB;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) glds16(kp + (size_t)(32 * ps) * ldq, sk + ps * 4096);
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) glds16(vp + (size_t)(32 * ps) * Tp, sv + ps * 4096);
+    };
+    // fragment addresses inside a tile.  K: row = 32 m + 8 xy + i + (i & 8), chunk 4 ks + g; V^T: row = 16 db + i, chunk 4 m + g
+    const int krow = j15 + (j15 & 8);                              // + 32 m + 8 xy
+    const int kb_g = (g & 1) * 4 + (g >> 1) * 16;                  // first key (inside a half, X block) of this lane's quad
+    auto k_addr = [&](int m, int xy, int ks) {
+        const int r = 32 * m + 8 * xy + krow;
+        const int f = ((r >> 1) & 3) | (((r >> 4) & 1) << 2);
+        return r * 128 + (((4 * ks + g) ^ f) * 16);
+    };
+    auto v_addr = [&](int m, int db) {
+        const int r = 16 * db + j15;
+        return r * 128 + (((4 * m + g) ^ ((r >> 1) & 7)) * 16);
+    };
+
+    f32x4 o[4][2];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) o[db][qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_ref[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+    bool bad = false;
+    const bool tail1 = (T & (KB - 1)) == 1 && T > KB;
+    const int ntile = tail1 ? T / KB : (T + KB - 1) / KB;
+    stage(0, 0);
+    int buf = 0, nbuf = 1;
+    for (int jt = 0; jt < ntile; ++jt) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const char* sk = smem + buf * (2 * KV_TILE_BYTES);
+        const char* sv = sk + KV_TILE_BYTES;
+        const int nbuf_now = nbuf;
+        buf ^= 1;
+        nbuf ^= 1;
+        if (!active) {
+            stage(jt + 1 < ntile ? jt + 1 : ntile - 1, nbuf_now);
+            continue;
+        }
+        // ---- S^T = K . Q^T - m_ref : s[m][xy][qb], lane (j, g) <- keys 32 m + 8 xy + kb_g + 0..3 of query 16 qb + j ----
+        f32x4 sc[2][2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int xy = 0; xy < 2; ++xy)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) sc[m][xy][qb] = (f32x4){-m_ref[qb], -m_ref[qb], -m_ref[qb], -m_ref[qb]};
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            V8 kf[2][2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int xy = 0; xy < 2; ++xy) kf[m][xy] = *(const V8*)(sk + k_addr(m, xy, ks));
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int xy = 0; xy < 2; ++xy)
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) sc[m][xy][qb] = Op<DT>::mfma16(kf[m][xy], qf[qb][ks], sc[m][xy][qb]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        stage(jt + 1 < ntile ? jt + 1 : ntile - 1, nbuf_now);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- mask keys >= T (only the last tile can contain them) ----
+        if (jt * KB + KB > T) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int xy = 0; xy < 2; ++xy)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (jt * KB + 32 * m + 8 * xy + kb_g + r >= T) { sc[m][xy][0][r] = -INFINITY; sc[m][xy][1][r] = -INFINITY; }
+        }
+        // ---- reference level: the exact row maximum of tile 0 (over the four lanes of a query), then fixed ----
+        if (jt == 0) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                float mt = sc[0][0][qb][0];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int xy = 0; xy < 2; ++xy)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mt = fmaxf(mt, sc[m][xy][qb][r]);
+                mt = fmaxf(mt, __shfl_xor(mt, 16));
+                mt = fmaxf(mt, __shfl_xor(mt, 32));
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int xy = 0; xy < 2; ++xy)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sc[m][xy][qb][r] -= mt;
+                m_ref[qb] = mt;
+            }
+        }
+        // ---- p = exp2(s - m_ref) ----
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int xy = 0; xy < 2; ++xy)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[m][xy][qb][r] = __builtin_amdgcn_exp2f(sc[m][xy][qb][r]);
+        // ---- O^T += V^T . P^T ; row sums from the rounded values (v_dot2 of each packed pair against (1, 1)) ----
+        float psum[2] = {0.f, 0.f};
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            V8 pf[2];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { pf[qb][e] = (Tt)sc[m][0][qb][e]; pf[qb][4 + e] = (Tt)sc[m][1][qb][e]; }
+                const u32x4 pw = __builtin_bit_cast(u32x4, pf[qb]);
+                psum[qb] = Op<DT>::pair_sum(pw[0], psum[qb]);
+                psum[qb] = Op<DT>::pair_sum(pw[1], psum[qb]);
+                psum[qb] = Op<DT>::pair_sum(pw[2], psum[qb]);
+                psum[qb] = Op<DT>::pair_sum(pw[3], psum[qb]);
+            }
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const V8 vf = *(const V8*)(sv + v_addr(m, db));
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) o[db][qb] = Op<DT>::mfma16(vf, pf[qb], o[db][qb]);
+            }
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            l_run[qb] += psum[qb];
+            bad |= !(psum[qb] <= limit);          // all p > 0: a lane sum <= limit proves every p of the lane finite in 16 bits
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    if (tail1 && active) {
+        // the lone key T - 1 as a rank-1 update (fp32 p; its V row through a wave-private LDS strip), closed over a query's four lanes
+        int kl = T - 1, lane2 = lane;
+        asm volatile("" : "+s"(kl), "+v"(lane2));
+        const int g2 = lane2 >> 4;
+        const Tt* kp = qk + (row0 + kl) * ldq + C + h * 64 + 8 * g2;
+        float dot[2] = {0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const V8 kf = *(const V8*)(kp + 32 * ks);
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dot[qb] = __builtin_fmaf((float)qf[qb][ks][e], (float)kf[e], dot[qb]);
+        }
+        const int klp = (kl & ~12) | ((kl & 4) << 1) | ((kl & 8) >> 1);          // V^T columns are key-permuted (bits 2 <-> 3)
+        float* vl = (float*)(smem + 2 * 2 * KV_TILE_BYTES) + w * 64;
+        vl[lane2] = (float)vt[((size_t)(b * H + h) * 64 + lane2) * Tp + klp];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        // the strip is written and read by this wave only
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float d = dot[qb];
+            d += __shfl_xor(d, 16);
+            d += __shfl_xor(d, 32);
+            const float p = __builtin_amdgcn_exp2f(d - m_ref[qb]);
+            bad |= !(p <= limit);
+            if (g2 == 0) l_run[qb] += p;                                          // (the row sum is the sum over the query's four lanes)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const f32x4 v4 = *(const f32x4*)(vl + 16 * db + 4 * g2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[db][qb][e] = __builtin_fmaf(v4[e], p, o[db][qb][e]);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        const bool anybad = __any(bad);
+        if (lane == 0) flags[4 * bid + w] = anybad ? 1 : 0;
+    }
+    // ---- normalise and store: lane (j, g) holds O[16 qb + j][16 db + 4 g + 0..3] ----
+    if (!in_buf) return;
+    int lane3 = lane;
+    asm volatile("" : "+v"(lane3));
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        float l_tot = l_run[qb];
+        l_tot += __shfl_xor(l_tot, 16);
+        l_tot += __shfl_xor(l_tot, 32);
+        const float inv = active ? 1.0f / l_tot : 0.f;
+        Tt* op = (Tt*)out_ + (row0 + (qt * QB + 32 * w + 16 * qb + (lane3 & 15))) * C + h * 64 + 4 * (lane3 >> 4);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            V4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (Tt)(o[db][qb][e] * inv);
+            *(V4*)(op + 16 * db) = v;
+        }
+    }
+}
+
+int launch_attn16(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit, int* flags,
+                  hipStream_t s) {
+    const int nqt = (Tp + 127) / 128;
+    const int grid = nqt * H * B;
+    const size_t lds = 2 * 2 * KV_TILE_BYTES + 4 * 256;
+    if (dtype == MHMR_DT_F16)
+        hipLaunchKernelGGL((attn16_kernel<MHMR_DT_F16>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags);
+    else
+        hipLaunchKernelGGL((attn16_kernel<MHMR_DT_BF16>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int RING>
 int launch_attn64(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit, int* flags,
                   hipStream_t s) {
@@ -703,7 +976,7 @@ int mhmr_attention_flag_count_impl(int B, int Tp, int H) { return 4 * ((Tp + 127
 int mhmr_launch_attention_ex(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit_log2,
                              int variant, int* flags, hipStream_t s) {
     if (C != H * 64 || Tp % 64 || T > Tp || T <= 0 || limit_log2 < 0.f || limit_log2 > 15.f) return MHMR_ERR_BAD_SHAPE;
-    if (variant == 0 && flags == nullptr) return MHMR_ERR_BAD_ARG;
+    if ((variant == 0 || variant == 6) && flags == nullptr) return MHMR_ERR_BAD_ARG;
     const float limit = exp2f(limit_log2);
     prof_begin(PROF_ATTN, s);
     int rc = 0;
@@ -721,6 +994,12 @@ int mhmr_launch_attention_ex(const void* qk, const void* vt, void* out, int B, i
             if (flags == nullptr) return MHMR_ERR_BAD_ARG;
             rc = variant == 4 ? launch_attn64<3>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s)
                               : launch_attn64<2>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
+            if (!rc) rc = launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
+            break;
+        }
+        case 6: {     // MODE 3 arithmetic on v_mfma_f32_16x16x32 (attn16_kernel) + the gated textbook fallback
+            if (flags == nullptr) return MHMR_ERR_BAD_ARG;
+            rc = launch_attn16(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
             if (!rc) rc = launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
             break;
         }

@@ -386,7 +386,7 @@ def _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=None, variant=0):
     else:
         flags = torch.full((L.mhmr_attention_flag_count(B, Tp, H),), 7, dtype=torch.int32, device=dev())   # (the call writes every entry)
         _lib.check(L.mhmr_attention16_ex(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), B, T, Tp, C, H, dt, thr, variant,
-                                         flags.data_ptr() if variant in (0, 4, 5) else None, stream()), "attention_ex")
+                                         flags.data_ptr() if variant in (0, 4, 5, 6) else None, stream()), "attention_ex")
         _attn_run.last_flags = flags
     return out.view(B, Tp, C)
 
@@ -400,7 +400,7 @@ def _attn_ref(q, k, v, T, rows=None):
 
 
 @pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
-@pytest.mark.parametrize("variant", [None, 0, 4, 5])     # None = mhmr_attention16; 0 = 32 queries per wave; 4 / 5 = 64 queries per wave
+@pytest.mark.parametrize("variant", [None, 0, 4, 5, 6])     # None = mhmr_attention16; 0 = 32 queries per wave; 4 / 5 = 64 queries per wave; 6 = 16x16x32 MFMAs
 @pytest.mark.parametrize("B,H,T,pad", [(2, 3, 200, 128), (1, 2, 256, 128), (1, 1, 65, 128), (2, 6, 257, 128), (2, 6, 257, 64), (3, 2, 130, 64),
                                        (1, 2, 577, 64), (2, 1, 40, 64)])
 def test_attention(L, name, dt, tdt, tol, B, H, T, pad, variant):
@@ -413,7 +413,7 @@ def test_attention(L, name, dt, tdt, tol, B, H, T, pad, variant):
 
 
 @pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
-@pytest.mark.parametrize("variant", [0, 4, 5])
+@pytest.mark.parametrize("variant", [0, 4, 5, 6])
 @pytest.mark.parametrize("target", [10.0, 40.0])
 def test_attention_last_key_rank_one_update(L, name, dt, tdt, tol, target, variant):
     """T = 64 n + 1: the default kernel form folds the lone key of the last tile in as a rank-1 update.  A last key that dominates
@@ -433,7 +433,7 @@ def test_attention_last_key_rank_one_update(L, name, dt, tdt, tol, target, varia
     assert err < (4e-3 if name == "f16" else 3e-2), err
 
 
-@pytest.mark.parametrize("variant", [0, 4])
+@pytest.mark.parametrize("variant", [0, 4, 6])
 @pytest.mark.parametrize("pad", [128, 64])               # rows per image: 2432 / 4224 / 8576 or 2368 / 4160 / 8512 (vit.padded_tokens)
 @pytest.mark.parametrize("T", [2305, 4097, 8465])        # 672^2, 896^2, 1288^2: 37 / 65 / 133 key tiles, the last one masked
 def test_attention_full_length_against_fp64(L, T, pad, variant):
@@ -481,13 +481,14 @@ def test_attention_reference_level_branches_are_exact(L, name, dt, tdt, tol):
         assert err < bound, (lim, err)
     for lim in (15.0, 6.0):      # same function, different rounding order: at most one output ulp apart (|O| <= ~4)
         assert float((outs[lim] - outs[0.0]).abs().max()) <= (2.0 ** -8 if name == "f16" else 2.0 ** -5), lim
-    for variant in (1, 2, 4, 5):       # the A/B forms compute the same function
+    for variant in (1, 2, 4, 5, 6):       # the A/B forms compute the same function
         got = _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=15.0, variant=variant)[:, :T].double()
         assert float((got - ref).abs().max()) < bound, variant
-    for lim in (0.0, 6.0):             # 64 queries per wave: the flag path (workgroup numbering of the fallback kernel) at low limits
-        got = _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=lim, variant=4)[:, :T].double()
-        assert float((got - ref).abs().max()) < bound, ("v4", lim)
-        assert float((got - outs[0.0]).abs().max()) <= (2.0 ** -8 if name == "f16" else 2.0 ** -5), ("v4", lim)
+    for var in (4, 6):                 # 64 queries per wave / 16x16x32 MFMAs: the flag path (workgroup numbering of the fallback kernel) at low limits
+        for lim in (0.0, 6.0):
+            got = _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=lim, variant=var)[:, :T].double()
+            assert float((got - ref).abs().max()) < bound, (var, lim)
+            assert float((got - outs[0.0]).abs().max()) <= (2.0 ** -8 if name == "f16" else 2.0 ** -5), (var, lim)
 
 
 # ------------------------------------------------------------------------------------------------------ norms, patchify
