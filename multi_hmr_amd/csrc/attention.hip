@@ -721,18 +721,15 @@ __global__ __launch_bounds__(256, 4) void attn16_kernel(const void* __restrict__
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) glds16(vp + (size_t)(32 * ps) * Tp, sv + ps * 4096);
     };
-    // fragment addresses inside a tile.  K: row = 32 m + 8 xy + i + (i & 8), chunk 4 ks + g; V^T: row = 16 db + i, chunk 4 m + g
-    const int krow = j15 + (j15 & 8);                              // + 32 m + 8 xy
+    // fragment addresses inside a tile.  K: row = 32 m + 8 xy + i + (i & 8), chunk 4 ks + g; V^T: row = 16 db + i, chunk 4 m + g.  Both
+    // swizzle terms depend on the lane only ((32 m + 8 xy) and 16 db leave the bits they use alone), and chunk 4 + c is chunk c with bit 2
+    // flipped: two lane offsets per tile, everything else is an immediate offset of the ds_read
+    const int krow = j15 + (j15 & 8);
     const int kb_g = (g & 1) * 4 + (g >> 1) * 16;                  // first key (inside a half, X block) of this lane's quad
-    auto k_addr = [&](int m, int xy, int ks) {
-        const int r = 32 * m + 8 * xy + krow;
-        const int f = ((r >> 1) & 3) | (((r >> 4) & 1) << 2);
-        return r * 128 + (((4 * ks + g) ^ f) * 16);
-    };
-    auto v_addr = [&](int m, int db) {
-        const int r = 16 * db + j15;
-        return r * 128 + (((4 * m + g) ^ ((r >> 1) & 7)) * 16);
-    };
+    const int kf_sw = g ^ (((krow >> 1) & 3) | (((krow >> 4) & 1) << 2));
+    const int vf_sw = g ^ ((j15 >> 1) & 7);
+    int kofs[2] = {krow * 128 + kf_sw * 16, krow * 128 + (kf_sw ^ 4) * 16};           // [ks]
+    int vofs[2] = {j15 * 128 + vf_sw * 16, j15 * 128 + (vf_sw ^ 4) * 16};             // [m]
 
     f32x4 o[4][2];
 #pragma unroll
@@ -768,19 +765,17 @@ __global__ __launch_bounds__(256, 4) void attn16_kernel(const void* __restrict__
                 for (int qb = 0; qb < 2; ++qb) sc[m][xy][qb] = (f32x4){-m_ref[qb], -m_ref[qb], -m_ref[qb], -m_ref[qb]};
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            V8 kf[2][2];
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 2; ++m) {
+                V8 kf[2];
 #pragma unroll
-                for (int xy = 0; xy < 2; ++xy) kf[m][xy] = *(const V8*)(sk + k_addr(m, xy, ks));
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
+                for (int xy = 0; xy < 2; ++xy) kf[xy] = *(const V8*)(sk + kofs[ks] + (32 * m + 8 * xy) * 128);
 #pragma unroll
                 for (int xy = 0; xy < 2; ++xy)
 #pragma unroll
-                    for (int qb = 0; qb < 2; ++qb) sc[m][xy][qb] = Op<DT>::mfma16(kf[m][xy], qf[qb][ks], sc[m][xy][qb]);
-        }
+                    for (int qb = 0; qb < 2; ++qb) sc[m][xy][qb] = Op<DT>::mfma16(kf[xy], qf[qb][ks], sc[m][xy][qb]);
+            }
         __builtin_amdgcn_s_setprio(0);
         stage(jt + 1 < ntile ? jt + 1 : ntile - 1, nbuf_now);
         __builtin_amdgcn_sched_barrier(0);
@@ -843,7 +838,7 @@ __global__ __launch_bounds__(256, 4) void attn16_kernel(const void* __restrict__
             }
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                const V8 vf = *(const V8*)(sv + v_addr(m, db));
+                const V8 vf = *(const V8*)(sv + vofs[m] + db * 2048);
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) o[db][qb] = Op<DT>::mfma16(vf, pf[qb], o[db][qb]);
             }
