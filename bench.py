@@ -278,7 +278,7 @@ def main():
         n_a, ms_a, _ = prof_collect()
         att_tf = attn_fl * B * reps / (ms_a * 1e-3) / 1e12 if ms_a > 0 else 0.0
         result["roofline_attention"] = {
-            "kernel": "attn_kernel (flash, d=64; reference level in the accumulator init)", "bound": "mfma", "achieved": round(att_tf, 1),
+            "kernel": "attn16_kernel (flash, d=64, v_mfma_f32_16x16x32; reference level in the accumulator init)", "bound": "mfma", "achieved": round(att_tf, 1),
             "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(att_tf / PEAK_MFMA_TFLOPS, 4),
             "traffic": pmc.get("_attention_bytes_per_call") if pmc else None, "launches": n_a,
             "avg_launch_ms": round(ms_a / max(n_a, 1), 4), "share_of_step": round(ms_a / reps / ms_step, 3)}

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define MHMR_VERSION 103   /* 103: mhmr_camera_embed(num_bands), mhmr_hph_desc.cam_dim; mhmr_lbs_consts.basis16 layout (high halves for k < Kb - 64); mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
+#define MHMR_VERSION 103   /* 103: mhmr_attention16_ex variant 6 (the default of mhmr_vit_forward); mhmr_camera_embed(num_bands), mhmr_hph_desc.cam_dim; mhmr_lbs_consts.basis16 layout (high halves for k < Kb - 64); mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
 
 #define MHMR_OK 0
 #define MHMR_ERR_BAD_ARG (-1)
@@ -142,7 +142,9 @@ int mhmr_attention16(const void* qk, const void* vt, void* out, int B, int T, in
                      void* stream);
 /* The attention kernel forms (csrc/attention.hip), for tests and A/B measurements.  Every form subtracts a per-query reference
  * level from the scores inside the matrix pipe; they differ in how the level follows the row maximum:
- *   variant 0  (what mhmr_vit_forward runs) level = exact row maximum of key tile 0, no maximum afterwards; a workgroup in which
+ *   variant 6  (what mhmr_vit_forward runs since round 4) the arithmetic and flag protocol of variant 0 on v_mfma_f32_16x16x32 (a query's
+ *              keys spread over four lanes; the 32x32x16 shape of the other forms costs 5-8 % more power per flop on this chip).
+ *   variant 0  level = exact row maximum of key tile 0, no maximum afterwards; a workgroup in which
  *              a lane's tile sum of exp2(score - level) exceeded 2^limit_log2 (0 <= limit_log2 <= 15; 15 = "would leave the
  *              16-bit range", 0 = nearly every workgroup) sets its entries of `flags` and is recomputed by variant 1, launched
  *              right behind it on the same stream.  flags: int workspace of mhmr_attention_flag_count(B, Tp, H) entries (four

@@ -39,6 +39,11 @@
 // (ROCm 7.2) does NOT emit the vmcnt wait for LDS-DMA in front of __syncthreads() -- it hoisted it out of the loop -- and
 // the kernel then read tiles that had not landed (run-to-run different results; tools/determinism.py).
 //
+// Round 4: mhmr_vit_forward runs attn16_kernel (variant 6, further down): the MODE 3 arithmetic of this file on v_mfma_f32_16x16x32 -- the
+// 32x32x16 shape used by the kernels up here costs 5-8 % more power per flop on this power-clocked chip.  1116-1128 against 973-1048 TF/s
+// alone, 1052-1059 against 1015 inside the forward (f16, one box, interleaved: profiles/r04_session_i_attention_16x16x32.txt).  The forms
+// above stay as selectable variants (0-5) with their tests; MODE 1 remains the fallback of every gated form.
+//
 // Measured and rejected on the MODE 3 form (B = 32, H = 16, T = 4097, same process, interleaved): K fragments double-buffered one
 // k-step ahead with pinned issue order (120 VGPRs) 933-936 vs 900-953 TFLOP/s f16 for this form, 990-997 vs 945-1016 bf16; 8 waves
 // with a 3-slot ring 862-908; both together 954 / 1006: all inside the run-to-run spread of the plain 4-wave form, which stays.
@@ -57,7 +62,7 @@ __device__ __forceinline__ float max_lane32(float v) {
 
 constexpr int KB = 64;
 #ifndef MHMR_ATTN_DEFAULT_VARIANT
-#define MHMR_ATTN_DEFAULT_VARIANT 0          // what mhmr_vit_forward runs (MHMR_ATTN_VARIANT overrides at run time: A/B measurements)
+#define MHMR_ATTN_DEFAULT_VARIANT 6          // what mhmr_vit_forward runs (MHMR_ATTN_VARIANT overrides at run time: A/B measurements)
 #endif
 constexpr int KV_TILE_BYTES = KB * 64 * 2;  // 8 KiB
 constexpr float BAND = 8.f;                 // MODE 2: half-width of the band around the reference level (exp2 domain)
@@ -962,7 +967,8 @@ int mhmr_attention_flag_count_impl(int B, int Tp, int H) { return 4 * ((Tp + 127
 // limit_log2 (variant 0): a workgroup is recomputed by the textbook kernel when a lane's tile sum of exp2(s - level) exceeded
 // 2^limit_log2 (0 <= limit_log2 <= 15; 15 = the shipped value "would leave the 16-bit range", 0 = nearly every workgroup).
 // variant: 0 = MODE 3 + gated MODE 1 fallback (needs `flags`), 1 = textbook (MODE 1), 2 = banded running maximum (MODE 2),
-// 3 = MODE 2 with 8-wave workgroups, 4 / 5 = 64 queries per wave (attn64_kernel, MODE 3 arithmetic + gated fallback; needs `flags`).
+// 3 = MODE 2 with 8-wave workgroups, 4 / 5 = 64 queries per wave (attn64_kernel, MODE 3 arithmetic + gated fallback; needs `flags`),
+// 6 = MODE 3 arithmetic on 16x16x32 MFMAs (attn16_kernel + gated fallback; needs `flags`): what mhmr_vit_forward runs.
 // Measured at ViT-L 896 b32, f16 / bf16 TFLOP/s (tools/kbench.py, interleaved rounds): textbook 855-875 / 895-929; banded
 // maximum 930-940 / 973-1003; the same with the level as a 16-register C tuple (3 waves per SIMD) 918-920 / 975; with all 8 K
 // fragments and the V^T fragments requested ahead of their MFMAs (sched_barrier-pinned; 3 waves per SIMD, or 4 with spills)

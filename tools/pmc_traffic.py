@@ -14,7 +14,7 @@ usage: tools/pmc_traffic.py <dir with FETCH_SIZE_counter_collection.csv, WRITE_S
 import collections, csv, glob, hashlib, json, os, re, sys
 d = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PAT = re.compile(r"(gemm256_kernel<[^>]*>|gemm_kernel<\d, \d>|cls_linear_kernel<[^>]*>|ln_stats_kernel|attn_kernel<[^>]*>|layernorm_kernel<[^>]*>|lbs_vertex_kernel|lbs_pose_kernel|lbs_extra_joints_kernel)")
+PAT = re.compile(r"(gemm256_kernel<[^>]*>|gemm_kernel<\d, \d>|cls_linear_kernel<[^>]*>|ln_stats_kernel|attn_kernel<[^>]*>|attn16_kernel<[^>]*>|attn64_kernel<[^>]*>|layernorm_kernel<[^>]*>|lbs_vertex_kernel|lbs_pose_kernel|lbs_extra_joints_kernel)")
 
 
 def find(dirname, counter):
@@ -77,7 +77,7 @@ gl = [(v["launches"], v["total_bytes_per_launch"]) for k, v in res.items() if k.
 if gl:
     res["_gemm_avg_bytes_per_launch"] = round(sum(n * b for n, b in gl) / sum(n for n, _ in gl))
 # one attention CALL = the main kernel + the (normally empty) fallback launch behind it
-al = sorted(((v["launches"], v["launches"] * v["total_bytes_per_launch"]) for k, v in res.items() if k.startswith("attn_kernel") and "launches" in v), reverse=True)
+al = sorted(((v["launches"], v["launches"] * v["total_bytes_per_launch"]) for k, v in res.items() if k.startswith(("attn_kernel", "attn16_kernel", "attn64_kernel")) and "launches" in v), reverse=True)
 if al:
     res["_attention_bytes_per_call"] = round(sum(b for _, b in al) / al[0][0])
 with open(os.path.join(ROOT, "multi_hmr_amd", "csrc", "libmhmr.so"), "rb") as f:
