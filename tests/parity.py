@@ -39,7 +39,8 @@ def tolerance(key, precision):
 
 #: max-norm gate of the full-size parity tests (tests/test_gpu_parity_fullsize.py).  Measured with f16 operands on the round-4 build
 #: (profiles/r04_parity_fullsize.json): every key of every BASELINE-size case is below 1e-3 EXCEPT `rotmat` -- the worst of 3816 ... 9540
-#: rotation-matrix entries (|ref|_inf = 1) is 0.9e-3 / 1.0e-3 / 1.8e-3 at 896^2 / 672^2 / 1288^2: a ~3.5-sigma draw of an error whose
+#: rotation-matrix entries (|ref|_inf = 1) is 1.2e-3 / 0.9e-3 / 1.6e-3 at 896^2 / 672^2 / 1288^2 (0.9e-3 / 1.0e-3 / 1.8e-3 before the attention kernel
+#: changed its MFMA shape: the value moves with every change of rounding order): a ~3.5-sigma draw of an error whose
 #: rms is 3e-4 -- and, on the hostile-mean golden, `v2d` (1.7e-3).  The gate is therefore 2e-3: the max-norm form of the 1e-3 contract
 #: is NOT met on those two keys, and this constant says by how much.
 MAXTOL = {"f16": 2e-3, "bf16": 4e-2}
