@@ -280,3 +280,18 @@ def test_bench_starts_its_own_ranks_and_refuses_more_gpus_than_the_node_has():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert "error" in d and d["n_gpus"] == 2 and d["gpus_visible"] == torch.cuda.device_count()
+
+
+def test_image_block_rule_of_the_backbone(smplx_data, mean_params):
+    """Model._nsplit: two image blocks when the batch is even, >= 8 images and the narrowest block linear is under six
+    rounds of 256 tiles -- BASELINE configs 2, 3, 5 -- one block for the headline (8 exact rounds) and for small batches; `split=` / MHMR_SPLIT
+    override it, and a count that does not divide the batch falls back to the next one that does."""
+    mk = lambda bb, S, **kw: Model(backbone=bb, img_size=S, smplx_data=smplx_data, mean_params=mean_params, backbone_depth=1, **kw)
+    assert mk("dinov2_vitl14", 896)._nsplit(32) == 1            # config 4, the bench default
+    assert mk("dinov2_vitl14", 672)._nsplit(32) == 2            # config 3
+    assert mk("dinov2_vitl14", 1288)._nsplit(8) == 2            # config 5
+    assert mk("dinov2_vits14", 672)._nsplit(16) == 2            # config 2
+    m = mk("dinov2_vitl14", 224)
+    assert m._nsplit(2) == 1 and m._nsplit(7) == 1 and m._nsplit(8) == 2
+    assert mk("dinov2_vitl14", 224, split=1)._nsplit(8) == 1 and mk("dinov2_vitl14", 224, split=4)._nsplit(8) == 4
+    assert mk("dinov2_vitl14", 224, split=4)._nsplit(6) == 3 and mk("dinov2_vitl14", 224, split=2)._nsplit(5) == 1
