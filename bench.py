@@ -86,7 +86,7 @@ def pmc_summary():
             except (OSError, ValueError):
                 continue
             if d.get("_source_hash") == lib_source_hash() or ("_source_hash" not in d and d.get("_lib_sha16") == lib_sha16()):
-                best = d
+                best = dict(d, _file=name)
     return best
 
 
@@ -126,13 +126,45 @@ def time_steps(fn, steps, warmup, dev):
     return time.perf_counter() - t0
 
 
+class _StubModel:
+    """MHMR_BENCH_STUB=1 (tests/test_bench_gloo.py): a CPU stand-in with the output contract of ``Model.forward(is_training=True)`` so that
+    the N > 1 CONTROL FLOW of this file -- per-step asynchronous collation, the barrier + max-over-ranks clock, rank 0's extra passes
+    against the other ranks' barrier, destroy_process_group -- runs under gloo without a GPU.  It measures nothing."""
+
+    def __init__(self, G, V=32):
+        self.G, self.V, self.calls = G, V, 0
+
+    def _nsplit(self, B):
+        return 1
+
+    def __call__(self, x, idx=None, K=None, is_training=True):
+        self.calls += 1
+        B, P = x.shape[0], idx[0].shape[0]
+        f = lambda *s: torch.full(s, float(self.calls), dtype=torch.float32)
+        return {"scores": torch.rand(B, self.G, self.G, 1), "loc": f(P, 2), "transl": f(P, 3), "transl_pelvis": f(P, 1, 3), "rotvec": f(P, 53, 3),
+                "expression": f(P, 10), "shape": f(P, 10), "j3d": f(P, 127, 3), "j2d": f(P, 127, 2), "v3d": f(P, self.V, 3)}
+
+
+class _HostEvent:
+    """torch.cuda.Event's interface on the host clock (stub mode)."""
+
+    def __init__(self, enable_timing=True):
+        self.t = 0.0
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return 1e3 * (other.t - self.t)
+
+
 def self_launch(n):
     """`python bench.py --gpus N` from a bare shell: start N ranks (one per GPU) of this same command under torch.distributed.run on a
     free local port and hand its exit code back.  More ranks than GPUs -> ONE JSON error line, exit code 2."""
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if n > have:
+    if n > have and os.environ.get("MHMR_BENCH_STUB") != "1":
         print(json.dumps({"error": f"--gpus {n} requested, {have} GPU(s) visible on this node", "n_gpus": n, "gpus_visible": have,
                           "metric": "images/sec (whole node)", "value": None}))
         return 2
@@ -167,23 +199,36 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    stub = os.environ.get("MHMR_BENCH_STUB") == "1"         # CPU + gloo + _StubModel: the control flow only (tests/test_bench_gloo.py)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if stub:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
     if world != args.gpus:
         if rank == 0:
             print(json.dumps({"error": f"--gpus {args.gpus} but WORLD_SIZE={world}", "n_gpus": args.gpus}))
         sys.exit(2)
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+    dev = torch.device("cpu") if stub else torch.device("cuda", local)
+    if not stub:
+        torch.cuda.set_device(dev)
+    Event = _HostEvent if stub else torch.cuda.Event
+    sync = (lambda: None) if stub else (lambda: torch.cuda.synchronize(dev))
 
     S, B, q = args.img_size, args.batch, args.persons
     cfg = synthetic.VIT_CFG[args.backbone]
-    smplx_data, mean_params = synthetic.make_smplx_data(0), synthetic.make_mean_params(0)
-    model = build_model(args.backbone, S, args.dtype, smplx_data, mean_params, dev)
-    x, K, idx = make_inputs(B, S, q, rank, dev)
+    if stub:
+        smplx_data = mean_params = None
+        model = _StubModel(S // 14)
+        x, K = torch.zeros(B, 3, 1, 1), torch.zeros(B, 3, 3)
+        idx = synthetic.make_pinned_idx(B, S // 14, q, seed=rank)
+    else:
+        smplx_data, mean_params = synthetic.make_smplx_data(0), synthetic.make_mean_params(0)
+        model = build_model(args.backbone, S, args.dtype, smplx_data, mean_params, dev)
+        x, K, idx = make_inputs(B, S, q, rank, dev)
 
     pending = []          # N > 1: the collation of step i travels over xGMI while step i + 1 computes (waited one step later)
     compute_ev = []       # N > 1: hipEvent pairs around the forward alone (separates compute from exposed collation)
@@ -194,7 +239,7 @@ def main():
 
     def step():
         if world > 1:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = Event(enable_timing=True), Event(enable_timing=True)
             e0.record()
         idx = idx_steps[step_no[0] % len(idx_steps)]
         step_no[0] += 1
@@ -215,7 +260,7 @@ def main():
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize(dev)
+        sync()
 
     for _ in range(args.warmup):
         step()
@@ -246,7 +291,7 @@ def main():
                                f"{q} pinned persons/image -> HPH (depth 2) -> SMPL-X LBS; image-sharded x{world}",
                    "global_batch": world * B, "parallelism": f"dp{world} (images)"},
         "mfma_utilisation_whole_forward": round((gemm_fl + attn_fl) * B * args.steps / dt / 1e12 / PEAK_MFMA_TFLOPS, 4),
-        "lib_sha16": lib_sha16(), "source_hash": lib_source_hash(),
+        "lib_sha16": None if stub else lib_sha16(), "source_hash": None if stub else lib_source_hash(),
         "backbone_image_blocks": model._nsplit(B),
     }
     if world > 1:
@@ -254,8 +299,14 @@ def main():
                                "exposed_collation_ms_per_step": round(ms_step - compute_ms / args.steps, 3),
                                "collation": "async RCCL all_gather of counts + padded person records, overlapped with the next step"}
 
-    if rank == 0:
+    if rank == 0 and stub:
+        # stub mode: rank 0's extra passes are a few more calls of the stand-in (the other ranks wait at the barrier below)
+        for _ in range(4):
+            model(x, idx=idx, K=K, is_training=True)
+        result["stub"] = True
+    if rank == 0 and not stub:
         # ---- profiled passes, OUTSIDE the timed region: hipEvent brackets around every GEMM / attention launch ----
+        # `launches`, `algorithmic_flops_per_launch`, `share_of_step` are PER FORWARD (the brackets run over `profiled_forwards` forwards)
         reps = 2
         prof_window(0)
         for _ in range(reps):
@@ -263,10 +314,14 @@ def main():
         n_gemm, ms_gemm, work_gemm = prof_collect()
         gemm_tf = gemm_fl * B * reps / (ms_gemm * 1e-3) / 1e12 if ms_gemm > 0 else 0.0
         pmc = pmc_summary()
+        pmc_src = ("profiles/" + pmc["_file"]) if pmc else None
         result["roofline"] = {
             "kernel": "gemm256_kernel (persistent 256x256x64 8-phase, v_mfma_f32_16x16x32; all ViT linears + heads)", "bound": "mfma",
             "achieved": round(gemm_tf, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tf / PEAK_MFMA_TFLOPS, 4),
-            "traffic": pmc.get("_gemm_avg_bytes_per_launch") if pmc else None, "launches": n_gemm,
+            "traffic": pmc.get("_gemm_avg_bytes_per_launch") if pmc else None,
+            "traffic_source": pmc_src, "traffic_note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch, committed summary of a run of these "
+                                                       "same sources (matched by source_hash); null when no summary matches",
+            "launches": n_gemm // reps, "profiled_forwards": reps,
             "avg_launch_ms": round(ms_gemm / max(n_gemm, 1), 4), "algorithmic_flops_per_launch": round(gemm_fl * B * reps / max(n_gemm, 1)),
             "share_of_step": round(ms_gemm / reps / ms_step, 3),
             # what the matrix pipe executed in those launches: 2 M N K as launched, i.e. with the low-half weight passes (k doubled
@@ -280,20 +335,24 @@ def main():
         result["roofline_attention"] = {
             "kernel": "attn16_kernel (flash, d=64, v_mfma_f32_16x16x32; reference level in the accumulator init)", "bound": "mfma", "achieved": round(att_tf, 1),
             "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(att_tf / PEAK_MFMA_TFLOPS, 4),
-            "traffic": pmc.get("_attention_bytes_per_call") if pmc else None, "launches": n_a,
+            "traffic": pmc.get("_attention_bytes_per_call") if pmc else None, "traffic_source": pmc_src,
+            "launches": n_a // reps, "profiled_forwards": reps,
             "avg_launch_ms": round(ms_a / max(n_a, 1), 4), "share_of_step": round(ms_a / reps / ms_step, 3)}
-    if rank == 0 and world == 1 and not args.no_extras and not args.only_headline_kernels:
+    extras = rank == 0 and not stub and not args.no_extras and not args.only_headline_kernels
+    if extras and world == 1:
         result["inference_mode"] = inference_bench(model, x, K, out_last, B, q, dev, steps=min(args.steps, 20))
-    if rank == 0 and not args.no_extras and not args.only_headline_kernels:
+    if extras:
         result["lbs"] = lbs_bench(model, dev, P=160)
-        result["ms_per_person_lbs"] = result["lbs"]["ms_per_person"]
-        result["lbs_small_batches"] = {f"P={p}": lbs_bench(model, dev, P=p)["ms_per_person"] for p in (20, 1)}
+        small = {p: lbs_bench(model, dev, P=p) for p in (20, 1)}
+        # BASELINE.json's second metric at the three person counts of SURVEY 8(d), top level
+        result["ms_per_person_lbs"] = {"P=160": result["lbs"]["ms_per_person"], "P=20": small[20]["ms_per_person"], "P=1": small[1]["ms_per_person"]}
+        result["lbs_small_batches"] = {f"P={p}": {"ms_per_person": v["ms_per_person"], "layer_ms": v["layer_ms"]} for p, v in small.items()}
     if world > 1:
         torch.distributed.barrier()
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not stub and not args.no_cpu_baseline:
         result["cpu_baseline"], result["parity"] = cpu_baseline_and_parity(args, smplx_data, mean_params, model, x, K, idx, out_last)
-    if rank == 0 and world == 1 and not args.no_extras and not args.only_headline_kernels:
+    if extras and world == 1:
         # release the headline model's workspace before the other configurations
         del model, out_last
         torch.cuda.empty_cache()
@@ -307,10 +366,62 @@ def main():
         del m2
         torch.cuda.empty_cache()
         result["configs"] = [other_config(name, bb, s, b, p, args.dtype, smplx_data, mean_params, dev) for name, bb, s, b, p in OTHER_CONFIGS]
+        # the ONE runtime the reference publishes (README.md:87-93, measured at demo.py:333-338): batch-1 forward_model latency
+        result["latency_b1"] = latency_b1(args.dtype, smplx_data, mean_params, dev)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+#: reference README.md:87-91: per-image forward_model runtime, batch 1, fp16 autocast, on a V100 (ms)
+REFERENCE_V100_MS = {"multiHMR_896_L": 126.0, "multiHMR_672_L": 74.0, "multiHMR_672_B": 43.0, "multiHMR_672_S": 29.0}
+LATENCY_MODELS = [("multiHMR_896_L", "dinov2_vitl14", 896), ("multiHMR_672_L", "dinov2_vitl14", 672), ("multiHMR_672_B", "dinov2_vitb14", 672),
+                  ("multiHMR_672_S", "dinov2_vits14", 672)]
+
+
+def latency_b1(dtype, smplx_data, mean_params, dev, reps=30, persons=4):
+    """Batch-1 latency of ``demo.forward_model``'s path (reference demo.py:108-126, timed at demo.py:333-338 and published in README.md:
+    87-93 for a V100): ONE image resident in HBM, inference mode (detection + NMS on the model's own scores, HPH + SMPL-X for the
+    detected persons, the person-dict list), no batching.  `ms` = host wall clock around the call (it ends with the person-count
+    read-back, so the host clock is exact), `gpu_ms` = hipEvents around the same call on its stream; medians of `reps` calls."""
+    import torch.nn.functional as F
+    from multi_hmr_amd import demo
+    out = {}
+    for name, backbone, S in LATENCY_MODELS:
+        model = build_model(backbone, S, dtype, smplx_data, mean_params, dev)
+        x, K, idx = make_inputs(1, S, persons, 0, dev)
+        s = model(x, idx=idx, K=K, is_training=True)["scores"][..., 0]
+        m = F.max_pool2d(s[:, None], 3, stride=1, padding=1)[:, 0]
+        surv = torch.sort(s[m == s], descending=True).values
+        n = min(persons, surv.numel() - 1)
+        thr = float(0.5 * (surv[n - 1] + surv[n]))
+        run = lambda: demo.forward_model(model, x, K, det_thresh=thr, nms_kernel_size=3)
+        for _ in range(5):
+            humans = run()
+        torch.cuda.synchronize(dev)
+        wall, gpu = [], []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            run()
+            e1.record()
+            wall.append(time.perf_counter() - t0)
+            e1.synchronize()
+            gpu.append(e0.elapsed_time(e1))
+        cfg = synthetic.VIT_CFG[backbone]
+        gemm_fl, attn_fl = flops_per_image(S, cfg["embed_dim"], cfg["depth"])
+        med = sorted(wall)[len(wall) // 2]
+        out[name] = {"ms": round(1e3 * med, 3), "gpu_ms": round(sorted(gpu)[len(gpu) // 2], 3), "min_ms": round(1e3 * min(wall), 3),
+                     "persons": len(humans), "reps": reps,
+                     "mfma_utilisation_whole_forward": round((gemm_fl + attn_fl) / med / 1e12 / PEAK_MFMA_TFLOPS, 4),
+                     "reference_v100_fp16_ms": REFERENCE_V100_MS[name], "speedup_vs_reference_v100": round(REFERENCE_V100_MS[name] / (1e3 * med), 1)}
+        del model
+        torch.cuda.empty_cache()
+    out["note"] = ("batch 1, is_training=False through demo.forward_model, image already in HBM, seeded random weights; the reference's figures are "
+                   "README.md:87-91 (V100, fp16 autocast) -- other hardware, quoted for orientation, not a baseline this line is scored against")
+    return out
 
 
 def other_config(name, backbone, S, B, q, dtype, smplx_data, mean_params, dev, steps=10, warmup=3):

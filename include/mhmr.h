@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define MHMR_VERSION 103   /* 103: mhmr_attention16_ex variant 6 (the default of mhmr_vit_forward); mhmr_camera_embed(num_bands), mhmr_hph_desc.cam_dim; mhmr_lbs_consts.basis16 layout (high halves for k < Kb - 64); mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
+#define MHMR_VERSION 104   /* 104: mhmr_vit_desc.{x3, qkv32, hid32}: the f16x3 precision mode (three 16-bit products per term in every backbone linear, fp32 attention); mhmr_gemm16_ex a_k with K = 3 a_k; mhmr_attention_f32; 103: mhmr_attention16_ex variant 6 (the default of mhmr_vit_forward); mhmr_camera_embed(num_bands), mhmr_hph_desc.cam_dim; mhmr_lbs_consts.basis16 layout (high halves for k < Kb - 64); mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
 
 #define MHMR_OK 0
 #define MHMR_ERR_BAD_ARG (-1)
@@ -104,6 +104,18 @@ typedef struct {
      * are finished by a small kernel into `rowstats`; the consuming linears normalise in their epilogues. */
     float* pstats;          /* [B*Tp, C/64, 2]  (sum, sum of squares) of every 64-column block of a residual row               */
     float* rowstats;        /* [B*Tp, 2]        (mean, rstd)                                                                  */
+    /* x3 != 0: the "f16x3" precision mode -- for checkpoints whose statistics a single 16-bit rounding per operand does not survive
+     * (multi_hmr_amd/vit.py logit_gain).  Every operand of every backbone linear is an op16 PAIR (hi = op16(v), lo =
+     * op16(v - hi): 22 significant bits for f16) and every term is three products (a_hi w_hi + a_hi w_lo + a_lo w_hi) in one fp32
+     * accumulator chain of the same MFMA kernels (mhmr_gemm16_ex: K = 3 a_k); LayerNorm, GELU (exact erf), the residual stream and the
+     * WHOLE attention (mhmr_attention_f32) are fp32.  Layout changes against the fields above:
+     *   patch_w op16 [C, 3 Kp] and every block weight op16 [N, 3 K] = [W_hi | W_lo | W_hi] along k (qkv_w [3C, 3C], proj_w [C, 3C],
+     *   fc1_w [4C, 3C], fc2_w [C, 12C]); v_w2 / proj_w2 NULL, flags 0;  Tp % 128 == 0 (Tp % 256 for C % 256 == 0: every linear on the
+     *   256x256 kernel); a_patch op16 [roundup(B*N,128), 2 Kp], xn / att op16 [B*Tp, 2C], hid op16 [B*Tp, 8C] = [hi | lo];
+     *   qk, vt, attn_flags, pstats, rowstats unused (may be NULL). */
+    int x3;
+    float* qkv32;           /* x3: [B*Tp, 3C] fp32  (Q | K | V), bias included                                                 */
+    float* hid32;           /* x3: [B*Tp, 4C] fp32  fc1 output before the GELU                                                 */
 } mhmr_vit_desc;
 
 /* x: [B,3,S,S] fp32 (ImageNet-normalised).  feat32: [B*N, C] fp32 patch features (token n = y*G + x).
@@ -116,7 +128,9 @@ int mhmr_gemm16(const void* A, int lda, const void* W, int ldw, int M, int N, in
                 int dtype, void* stream);
 /* The same with (a) a token-row map: logical activation / output row m = b * img_rows + n lives at physical row b * img_stride + n
  * (img_rows % 256 == 0; 0 = rows are physical), so a GEMM can cover the patch rows of every image and skip its class / padding rows;
- * (b) a low-half weight pass: W = [W_hi | W_lo] along k, K = 2 * a_k, the activation's k index wraps at a_k (0 = off).            */
+ * (b) a low-half weight pass: W = [W_hi | W_lo] along k, K = 2 * a_k, the activation's k index wraps at a_k (0 = off);
+ * (c) K = 3 * a_k: W = [W_hi | W_lo | W_hi], A = [A_hi | A_lo] (lda >= 2 a_k): the third k range reads the activation's second a_k
+ *     columns -- three 16-bit products per term (the f16x3 mode).                                                                   */
 int mhmr_gemm16_ex(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias,
                    const float* gamma, void* out, int ldo, const float* pos, int Np, int Tp, int H, int Mvalid, int epi,
                    int dtype, int img_rows, int img_stride, int a_k, void* stream);
@@ -137,7 +151,10 @@ int mhmr_cls_linear16(const void* A, long long a_stride, const void* W, int ldw,
                       const float* gamma, void* out, long long o_stride, int n_base, int C, void* vt, int H, int Tp, int vcol,
                       int epi, int dtype, void* stream);
 /* qk: op16 [B*Tp, 2C] = (Q * MHMR_ATTN_QSCALE | K), head h at columns h*64; vt: op16 [B,H,64,Tp] key-permuted V^T
- * (MHMR_EPI_VT); out: op16 [B*Tp, C] = softmax_2(Q K^T) V over the T real keys of each image.                    */
+ * (MHMR_EPI_VT); out: op16 [B*Tp, C] = softmax_2(Q K^T) V over the T real keys of each image.
+ * `out` (here, in mhmr_attention16_ex and as mhmr_vit_desc.att) must be ZERO-INITIALISED ONCE by the caller: a 128-query workgroup whose
+ * rows are all padding (rows >= T of an image) returns without storing, so those rows keep what was allocated; the linears behind read
+ * them (row-local: real rows never depend on them) and NaN / Inf bit patterns there would be carried along.                       */
 int mhmr_attention16(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype,
                      void* stream);
 /* The attention kernel forms (csrc/attention.hip), for tests and A/B measurements.  Every form subtracts a per-query reference
@@ -158,6 +175,15 @@ int mhmr_attention16(const void* qk, const void* vt, void* out, int B, int T, in
 int mhmr_attention16_ex(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype,
                         float limit_log2, int variant, int* flags, void* stream);
 int mhmr_attention_flag_count(int B, int Tp, int H);
+/* The attention of the f16x3 mode (csrc/attention_f32.hip): qkv fp32 [B*Tp, 3C] = (Q | K | V) un-scaled, head h at columns h*64;
+ * out op16 PAIR [B*Tp, 2C] = [hi | lo] of softmax(Q K^T / 8) V over the T real keys; every product on v_mfma_f32_16x16x4_f32 (exact fp32).
+ * Rows >= T of an image are written as zeros or as the (finite) attention of a padding row: never left unwritten.   Tp % 64 == 0. */
+int mhmr_attention_f32(const float* qkv, void* out, int B, int T, int Tp, int C, int H, int dtype, void* stream);
+/* Producers of operand PAIRS in the f16x3 mode: out16 rows of 2 C (2 N) values = [hi = op16(y) | lo = op16(y - hi)].
+ * mhmr_layernorm16_pair: y = LayerNorm(in row) (C in {384, 768, 1024}); mhmr_gelu16_pair: y = gelu_erf(in[m][n]), in fp32 [M, N], N % 4 == 0. */
+int mhmr_layernorm16_pair(const float* in, const float* w, const float* b, void* out16, int rows, int C, float eps, int dtype,
+                          void* stream);
+int mhmr_gelu16_pair(const float* in, void* out16, long long M, int N, int dtype, void* stream);
 int mhmr_layernorm16(const float* in, const float* w, const float* b, void* out16, int rows, int C, float eps,
                      int dtype, void* stream);
 

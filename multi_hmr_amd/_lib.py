@@ -12,10 +12,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmhmr.so")
-SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "vit_misc.hip", "vit_cls.hip", "hph.hip", "lbs.hip", "preprocess.hip", "evalm.hip", "anny.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "attention_f32.hip", "vit_misc.hip", "vit_cls.hip", "hph.hip", "lbs.hip", "preprocess.hip", "evalm.hip", "anny.hip", "capi.hip"]
 HEADERS = ["mhmr_common.h", "mhmr_internal.h", os.path.join("..", "..", "include", "mhmr.h")]
 
-VERSION = 103                       # include/mhmr.h MHMR_VERSION (struct layouts and entry-point semantics)
+VERSION = 104                       # include/mhmr.h MHMR_VERSION (struct layouts and entry-point semantics)
 DT_BF16, DT_F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 EPI_OP16, EPI_OP16_GELU, EPI_OP16_RELU, EPI_RESID, EPI_PATCH, EPI_F32, EPI_VT, EPI_OP16_QK = range(8)
@@ -105,7 +105,8 @@ class VitDesc(C.Structure):
     _fields_ = ([(n, _i) for n in ("dtype", "B", "S", "C", "H", "L", "G", "N", "T", "Tp", "Kp")] +
                 [("patch_w", _vp), ("patch_b", _vp), ("cls_pos0", _vp), ("pos", _vp), ("blocks", C.POINTER(VitBlock)),
                  ("norm_w", _vp), ("norm_b", _vp)] +
-                [(n, _vp) for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid", "attn_flags", "pstats", "rowstats")])
+                [(n, _vp) for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid", "attn_flags", "pstats", "rowstats")] +
+                [("x3", _i), ("qkv32", _vp), ("hid32", _vp)])
 
 
 class HphLayer(C.Structure):
@@ -139,6 +140,9 @@ _SIGS = {
     "mhmr_attention16": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mhmr_attention16_ex": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp], _i),
     "mhmr_attention_flag_count": ([_i, _i, _i], _i),
+    "mhmr_attention_f32": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "mhmr_layernorm16_pair": ([_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp], _i),
+    "mhmr_gelu16_pair": ([_vp, _vp, C.c_longlong, _i, _i, _vp], _i),
     "mhmr_layernorm16": ([_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp], _i),
     "mhmr_detect_scores": ([_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "mhmr_detect_count": ([_vp, _i, _i, _i, _f, _vp, _vp], _i),

@@ -33,6 +33,10 @@ int mhmr_launch_cls_linear_fold(const void* A, long long a_stride, const void* W
                                 int dtype, const float* rowstats, long long rs_stride, const float* colsum, const float* fbias, void* x16,
                                 long long x_stride, hipStream_t s);
 int mhmr_launch_ln_stats(const float* pstats, const float* resid, float* rowstats, int B, int N, int Tp, int C, float eps, hipStream_t s);
+int mhmr_launch_attention_f32(const float* qkv, void* out, int B, int T, int Tp, int C, int H, int dtype, hipStream_t s);
+int mhmr_launch_im2col_pair(const float* x, void* a, int B, int S, int G, int Kp, int dtype, hipStream_t s);
+int mhmr_launch_layernorm_pair(const float* in, const float* w, const float* b, void* out16, int rows, int C, float eps, int dtype, hipStream_t s);
+int mhmr_launch_gelu_pair(const float* in, void* out, long long M, int N, int dtype, hipStream_t s);
 int mhmr_launch_loc(const float* offset, const int* det_y, const int* det_x, int patch, float* loc, int P, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------ profiler
@@ -169,12 +173,74 @@ int mhmr_layernorm16(const float* in, const float* w, const float* b, void* out1
     return mhmr_launch_layernorm(in, w, b, out16, rows, C, eps, dtype, (hipStream_t)stream);
 }
 
+int mhmr_attention_f32(const float* qkv, void* out, int B, int T, int Tp, int C, int H, int dtype, void* stream) {
+    if (!qkv || !out) return MHMR_ERR_BAD_ARG;
+    return mhmr_launch_attention_f32(qkv, out, B, T, Tp, C, H, dtype, (hipStream_t)stream);
+}
+
+int mhmr_layernorm16_pair(const float* in, const float* w, const float* b, void* out16, int rows, int C, float eps, int dtype, void* stream) {
+    return mhmr_launch_layernorm_pair(in, w, b, out16, rows, C, eps, dtype, (hipStream_t)stream);
+}
+int mhmr_gelu16_pair(const float* in, void* out16, long long M, int N, int dtype, void* stream) {
+    return mhmr_launch_gelu_pair(in, out16, M, N, dtype, (hipStream_t)stream);
+}
+
+// The f16x3 precision mode (include/mhmr.h, mhmr_vit_desc.x3): the same block structure with every linear as three 16-bit products per
+// term over operand PAIRS, fp32 LayerNorm / GELU / attention / residual.  All B * Tp rows go through every linear (no token-row map, no
+// LayerNorm fold, no class-row kernel): this mode buys accuracy, at ~3x the matrix work and a 1/16-rate attention.
+static int vit_forward_x3(const mhmr_vit_desc* d, const float* x, float* feat32, void* ctx16, int ldctx, hipStream_t s) {
+    const int dt = d->dtype, B = d->B, C = d->C, Tp = d->Tp, M = B * Tp, Kp = d->Kp;
+    const int Mp = (B * d->N + 127) / 128 * 128;
+    if (!d->qkv32 || !d->hid32 || !d->a_patch || !d->resid || !d->xn || !d->att || !d->hid) return MHMR_ERR_BAD_ARG;
+    if (Tp % 128 || Kp % 128) return MHMR_ERR_BAD_SHAPE;
+    TRY(mhmr_launch_im2col_pair(x, d->a_patch, B, d->S, d->G, Kp, dt, s));
+    TRY(mhmr_launch_init_rows(d->resid, d->cls_pos0, B, d->T, Tp, C, s));
+    {
+        GemmArgs g{d->a_patch, 2 * Kp, d->patch_w, 3 * Kp, Mp, C, 3 * Kp, d->patch_b, nullptr, d->resid, C, d->pos, d->N, Tp, d->H,
+                   B * d->N, EPI_PATCH};
+        g.a_k = Kp;
+        TRY(mhmr_launch_gemm(g, dt, s));
+    }
+    for (int l = 0; l < d->L; ++l) {
+        const mhmr_vit_block& k = d->blocks[l];
+        if (k.flags || k.v_w2 || k.proj_w2) return MHMR_ERR_BAD_ARG;
+        // x = x + ls1 * proj(MHSA(norm1(x)))
+        TRY(mhmr_launch_layernorm_pair(d->resid, k.ln1_w, k.ln1_b, d->xn, M, C, 1e-6f, dt, s));
+        {
+            GemmArgs g{d->xn, 2 * C, k.qkv_w, 3 * C, M, 3 * C, 3 * C, k.qkv_b, nullptr, d->qkv32, 3 * C, nullptr, 0, Tp, d->H, M, EPI_F32};
+            g.a_k = C;
+            TRY(mhmr_launch_gemm(g, dt, s));
+        }
+        TRY(mhmr_launch_attention_f32(d->qkv32, d->att, B, d->T, Tp, C, d->H, dt, s));
+        {
+            GemmArgs g{d->att, 2 * C, k.proj_w, 3 * C, M, C, 3 * C, k.proj_b, k.ls1, d->resid, C, nullptr, 0, Tp, d->H, M, EPI_RESID};
+            g.a_k = C;
+            TRY(mhmr_launch_gemm(g, dt, s));
+        }
+        // x = x + ls2 * fc2(gelu(fc1(norm2(x))))
+        TRY(mhmr_launch_layernorm_pair(d->resid, k.ln2_w, k.ln2_b, d->xn, M, C, 1e-6f, dt, s));
+        {
+            GemmArgs g{d->xn, 2 * C, k.fc1_w, 3 * C, M, 4 * C, 3 * C, k.fc1_b, nullptr, d->hid32, 4 * C, nullptr, 0, Tp, d->H, M, EPI_F32};
+            g.a_k = C;
+            TRY(mhmr_launch_gemm(g, dt, s));
+        }
+        TRY(mhmr_launch_gelu_pair(d->hid32, d->hid, (long long)M, 4 * C, dt, s));
+        {
+            GemmArgs g{d->hid, 8 * C, k.fc2_w, 12 * C, M, C, 12 * C, k.fc2_b, k.ls2, d->resid, C, nullptr, 0, Tp, d->H, M, EPI_RESID};
+            g.a_k = 4 * C;
+            TRY(mhmr_launch_gemm(g, dt, s));
+        }
+    }
+    return mhmr_launch_final_norm(d->resid, d->norm_w, d->norm_b, ctx16, ldctx, feat32, B, d->N, Tp, C, 1e-6f, dt, s);
+}
+
 int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void* ctx16, int ldctx, void* stream) {
     if (!d || !x || !feat32 || !ctx16) return MHMR_ERR_BAD_ARG;
     if (d->S % 14 || d->G * 14 != d->S || d->N != d->G * d->G || d->T != d->N + 1 || d->Tp % 64 || d->Tp < d->T ||
         d->C != d->H * 64 || d->Kp % 64 || d->Kp < 588 || (d->C != 384 && d->C != 768 && d->C != 1024))
         return MHMR_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
+    if (d->x3) return vit_forward_x3(d, x, feat32, ctx16, ldctx, s);
     const int dt = d->dtype, B = d->B, C = d->C, N = d->N, Tp = d->Tp, M = B * Tp;
     const int Mp = (B * N + 127) / 128 * 128;
     // Token rows of an image: patches 0..N-1, the class token at row N, zero padding up to Tp (vit_misc.hip).  When the patch rows of

@@ -288,7 +288,7 @@ int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s) {
     if (g.epi == EPI_VT && (g.Tp % 64 || g.N % 64)) return MHMR_ERR_BAD_SHAPE;
     if (g.epi == EPI_VT && (g.img_rows > 0 ? g.img_rows : g.Tp) % BM && (g_force_gemm128 || !mhmr_gemm256_eligible(g))) return MHMR_ERR_BAD_SHAPE;   // (this kernel's row tile)
     if (g.img_rows > 0 && (g.img_rows % BM || g.M % g.img_rows || g.img_stride < g.img_rows || g.epi == EPI_PATCH)) return MHMR_ERR_BAD_SHAPE;
-    if (g.a_k > 0 && (g.a_k % BK || g.K != 2 * g.a_k || g.ldw < g.K)) return MHMR_ERR_BAD_SHAPE;
+    if (g.a_k > 0 && (g.a_k % BK || (g.K != 2 * g.a_k && g.K != 3 * g.a_k) || g.ldw < g.K || (g.K == 3 * g.a_k && g.lda < 2 * g.a_k))) return MHMR_ERR_BAD_SHAPE;
     if (g.epi == EPI_OP16_QK && g.N % 128) return MHMR_ERR_BAD_SHAPE;      // Q | K halves are whole 64-column blocks
     if (g.x16 || g.pstats || g.rowstats) {       // LayerNorm fold: 256x256 kernel only
         if (g_force_gemm128 || !mhmr_gemm256_eligible(g)) return MHMR_ERR_BAD_SHAPE;

@@ -564,7 +564,7 @@ bool mhmr_gemm256_eligible(const GemmArgs& g) {
     const uint64_t mphys = g.img_rows > 0 ? (uint64_t)(g.M / g.img_rows) * (uint64_t)g.img_stride : (uint64_t)g.M;
     if (g.epi == EPI_RESID && mphys * (uint64_t)g.ldo * 4u >= (1ull << 32)) return false;   // 32-bit residual offsets
     if (g.img_rows > 0 && (g.img_rows % 256 || g.M % g.img_rows || g.epi == EPI_PATCH)) return false;   // a tile never straddles two images
-    if (g.a_k > 0 && (g.a_k % 128 || g.K != 2 * g.a_k)) return false;
+    if (g.a_k > 0 && (g.a_k % 128 || (g.K != 2 * g.a_k && g.K != 3 * g.a_k))) return false;
     if (g.lda >= (1 << 22) || g.ldw >= (1 << 22)) return false;      // 32-bit operand offsets INSIDE a 256-row tile (tile bases are 64-bit)
     return g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && (g.epi != EPI_VT || g.Tp % 64 == 0);
 }

@@ -333,8 +333,9 @@ constexpr int LBS_ROW = LBS_TV * 8 * 2;                // bytes of one (k block,
 constexpr int LBS_EBYTES = (LBS_KB / 8 / LBS_NE) * 6 * LBS_ROW;       // one ring slot = one eighth of the tile's slice as an f16 PAIR: 36 KiB
 constexpr int LBS_EOPS = LBS_EBYTES / 1024 / LBS_NL;                  // 1-KiB copies per loader wave per eighth (pair form)
 // Precision of the blend (round 4): the first LBS_NE - 1 eighths (k < 448: pose correctives only, millimetres) carry the HIGH half of
-// the basis alone and are multiplied by the high half of the feature alone -- ONE product per term, |error| <= 2^-11 (|F| . |D|): a few
-// micrometres on a centimetre of pose corrective -- and the last eighth (k 448..511: the last pose columns and ALL shape / expression
+// the basis alone and are multiplied by the high half of the feature alone -- ONE product per term; BOTH factors are rounded (2^-11 each), so |error| <= 2^-10 sum |F| |D| over the
+// 448 terms (worst case tens of micrometres on the synthetic basis; rms 4e-6 m, worst 2.5e-5 m measured: the max-abs gate of
+// tests/test_gpu_kernels.py::test_lbs_max_abs_gate_160_persons_x_20_seeds is 5e-5 m = 0.05 mm) -- and the last eighth (k 448..511: the last pose columns and ALL shape / expression
 // directions, centimetres times |beta| up to 3) keeps the f16 pair and the three products (5e-7 m).  That is 180 instead of 432 blend
 // MFMAs per person group and tile, 162 instead of 288 KiB of basis per tile from HBM and LDS.
 constexpr int LBS_EBYTES_HI = LBS_EBYTES / 2;                         // an eighth with the high half only: 18 KiB

@@ -33,6 +33,8 @@ struct GemmArgs {
     unsigned img_magic = 0;  // floor(2^32 / (img_rows / 256)) + 1 (0 when img_rows == 256), set by mhmr_launch_gemm: image of row tile tm = umulhi(tm, img_magic)
     // Low-half weight pass: W = [W_hi | W_lo] along k (ldw >= K, K = 2 * a_k): k tiles >= a_k / 64 re-read the activation's k tiles
     // from the start, so acc = A . W_hi^T + A . W_lo^T in one accumulator chain.  0 = off.
+    // K = 3 * a_k (the f16x3 precision mode): W = [W_hi | W_lo | W_hi], A = [A_hi | A_lo] (lda >= 2 a_k): the k tiles of the third range
+    // read the activation's SECOND a_k columns, so acc = A_hi W_hi^T + A_hi W_lo^T + A_lo W_hi^T -- three 16-bit products per term.
     int a_k = 0;
     int colgroup = 0;        // gemm256: column-group tile order for wide outputs: log2 of the weight column panels an XCD keeps (2 = four panels, 3 = eight; 0 = off); set by mhmr_launch_gemm, MHMR_COLGROUP overrides
     // LayerNorm folded into the neighbouring GEMMs (gemm256 only): the LayerNorm pass of its own disappears.

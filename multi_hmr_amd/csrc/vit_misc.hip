@@ -8,7 +8,8 @@ namespace {
 
 // a_patch[m = (b*G + gy)*G + gx][k = c*196 + py*14 + px] = x[b][c][gy*14+py][gx*14+px]; k in [588, Kp) = 0.
 // One thread = 8 consecutive k of one patch (one 16-byte store).
-template <int DT>
+// PAIR (the f16x3 precision mode): rows of 2 Kp values, [hi = op16(x) | lo = op16(x - hi)]: the three-product A operand (GemmArgs::a_k, K = 3 a_k)
+template <int DT, bool PAIR = false>
 __global__ void im2col_kernel(const float* __restrict__ x, void* __restrict__ a_, int B, int S, int G, int Kp) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
@@ -20,6 +21,7 @@ __global__ void im2col_kernel(const float* __restrict__ x, void* __restrict__ a_
     const long long m = gid / kc;
     const int gx = (int)(m % G), gy = (int)((m / G) % G), b = (int)(m / ((long long)G * G));
     V8 v;
+    [[maybe_unused]] V8 lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int k = c8 * 8 + e;
@@ -29,8 +31,14 @@ __global__ void im2col_kernel(const float* __restrict__ x, void* __restrict__ a_
             f = x[(((size_t)b * 3 + c) * S + gy * 14 + py) * S + gx * 14 + px];
         }
         v[e] = (T)f;
+        if constexpr (PAIR) lo[e] = (T)(f - (float)v[e]);
     }
-    *(V8*)((T*)a_ + (size_t)m * Kp + c8 * 8) = v;
+    if constexpr (PAIR) {
+        *(V8*)((T*)a_ + (size_t)m * (2 * Kp) + c8 * 8) = v;
+        *(V8*)((T*)a_ + (size_t)m * (2 * Kp) + Kp + c8 * 8) = lo;
+    } else {
+        *(V8*)((T*)a_ + (size_t)m * Kp + c8 * 8) = v;
+    }
 }
 
 // Token rows of image b: patch n at row b*Tp + n (n < N = T - 1), the CLASS token LAST at row b*Tp + N, zero padding behind it.
@@ -53,7 +61,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // One wave per row; a lane holds NP vectors of VEC floats (C = NP * 64 * VEC; VEC = 4 -> 16-byte loads / 8-byte stores whenever
 // C % 256 == 0, VEC = 2 for C = 384).  Two-pass (mean, then centred variance) in registers.
-template <int DT, int NP, int VEC, bool FINAL>
+// PAIR: out16 rows of ld16 >= 2 C values, [hi = op16(y) | lo = op16(y - hi)] (the f16x3 precision mode)
+template <int DT, int NP, int VEC, bool FINAL, bool PAIR = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, const float* __restrict__ gw,
                                                         const float* __restrict__ gb, void* __restrict__ out16_, int ld16,
                                                         float* __restrict__ out32, int rows, int Np, int Tp, float eps) {
@@ -95,12 +104,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const fv w = *(const fv*)(gw + c), bb = *(const fv*)(gb + c);
         fv y;
         hv h;
+        [[maybe_unused]] hv hl;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             y[e] = v[i][e] * rstd * w[e] + bb[e];
             h[e] = (T)y[e];
+            if constexpr (PAIR) hl[e] = (T)(y[e] - (float)h[e]);
         }
         *(hv*)(o16 + c) = h;
+        if constexpr (PAIR) *(hv*)(o16 + C + c) = hl;
         if constexpr (FINAL) *(fv*)(out32 + out_row * C + c) = y;
     }
 }
@@ -153,13 +165,36 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
     }
 }
 
-template <int DT, bool FINAL>
+// exact-erf GELU of an fp32 matrix [M, N] -> the op16 pair [M, 2 N] = [hi | lo] (the f16x3 mode's fc2 operand); 4 values per thread
+template <int DT>
+__global__ __launch_bounds__(256) void gelu_pair_kernel(const float* __restrict__ in, void* __restrict__ out_, long long total4, int N) {
+    typedef typename Op<DT>::T T;
+    typedef typename Op<DT>::V4 V4;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total4) return;
+    const int n4 = N >> 2;
+    const long long m = gid / n4;
+    const int c = (int)(gid - m * n4) * 4;
+    const f32x4 v = *(const f32x4*)(in + m * N + c);
+    V4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float y = gelu_erf(v[e]);
+        hi[e] = (T)y;
+        lo[e] = (T)(y - (float)hi[e]);
+    }
+    T* o = (T*)out_ + m * (2LL * N) + c;
+    *(V4*)o = hi;
+    *(V4*)(o + N) = lo;
+}
+
+template <int DT, bool FINAL, bool PAIR = false>
 int launch_ln(const float* in, const float* w, const float* b, void* out16, int ld16, float* out32, int rows, int C,
               int Np, int Tp, float eps, hipStream_t s) {
     const int grid = (rows + 3) / 4;
 #define LN_CASE(CV, NPV, VECV)                                                                                           \
     case CV:                                                                                                             \
-        hipLaunchKernelGGL((layernorm_kernel<DT, NPV, VECV, FINAL>), dim3(grid), dim3(256), 0, s, in, w, b, out16, ld16, out32, \
+        hipLaunchKernelGGL((layernorm_kernel<DT, NPV, VECV, FINAL, PAIR>), dim3(grid), dim3(256), 0, s, in, w, b, out16, ld16, out32, \
                            rows, Np, Tp, eps);                                                                           \
         break;
     switch (C) {
@@ -183,6 +218,33 @@ int mhmr_launch_im2col(const float* x, void* a, int B, int S, int G, int Kp, int
         hipLaunchKernelGGL((im2col_kernel<MHMR_DT_F16>), dim3(grid), dim3(256), 0, s, x, a, B, S, G, Kp);
     else
         hipLaunchKernelGGL((im2col_kernel<MHMR_DT_BF16>), dim3(grid), dim3(256), 0, s, x, a, B, S, G, Kp);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+int mhmr_launch_im2col_pair(const float* x, void* a, int B, int S, int G, int Kp, int dtype, hipStream_t s) {
+    const long long total = (long long)B * G * G * (Kp / 8);
+    const int grid = (int)((total + 255) / 256);
+    if (dtype == MHMR_DT_F16)
+        hipLaunchKernelGGL((im2col_kernel<MHMR_DT_F16, true>), dim3(grid), dim3(256), 0, s, x, a, B, S, G, Kp);
+    else
+        hipLaunchKernelGGL((im2col_kernel<MHMR_DT_BF16, true>), dim3(grid), dim3(256), 0, s, x, a, B, S, G, Kp);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+int mhmr_launch_layernorm_pair(const float* in, const float* w, const float* b, void* out16, int rows, int C, float eps, int dtype,
+                               hipStream_t s) {
+    return dtype == MHMR_DT_F16 ? launch_ln<MHMR_DT_F16, false, true>(in, w, b, out16, 2 * C, nullptr, rows, C, 0, 0, eps, s)
+                                : launch_ln<MHMR_DT_BF16, false, true>(in, w, b, out16, 2 * C, nullptr, rows, C, 0, 0, eps, s);
+}
+
+int mhmr_launch_gelu_pair(const float* in, void* out, long long M, int N, int dtype, hipStream_t s) {
+    if (N % 4) return MHMR_ERR_BAD_SHAPE;
+    const long long total4 = M * (N / 4);
+    const int grid = (int)((total4 + 255) / 256);
+    if (dtype == MHMR_DT_F16) hipLaunchKernelGGL((gelu_pair_kernel<MHMR_DT_F16>), dim3(grid), dim3(256), 0, s, in, out, total4, N);
+    else hipLaunchKernelGGL((gelu_pair_kernel<MHMR_DT_BF16>), dim3(grid), dim3(256), 0, s, in, out, total4, N);
     MHMR_CHECK_LAUNCH();
     return 0;
 }

@@ -11,6 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import threading
 
 import numpy as np
 import torch
@@ -236,9 +237,12 @@ class Model(nn.Module):
         # always true, so the reference clamps the distance to [0, 50] whatever the argument says -- and so does hph_decode_kernel
         self.img_size, self.nearness, self.clip_dist = img_size, nearness, (clip_dist,)
         self.xat_depth, self.xat_num_heads, self.num_betas = xat_depth, xat_num_heads, num_betas
-        self.precision = kwargs.get("precision", os.environ.get("MHMR_PRECISION", "f16"))
-        if self.precision not in packing.OP_DTYPES:
-            raise ValueError(f"precision must be one of {list(packing.OP_DTYPES)}")
+        # MFMA operand format of the backbone: "f16" | "bf16" | "f16x3" (operand pairs, three products per term, fp32 attention: ~5x the
+        # time, for checkpoints a single 16-bit rounding per operand does not survive) | "auto" (the default: "f16" unless the
+        # weights' attention-logit statistic says otherwise, vit.logit_gain -- decided once, at pack time; `packed_precision` tells)
+        self.precision = kwargs.get("precision", os.environ.get("MHMR_PRECISION", "auto"))
+        if self.precision not in vit.PRECISIONS:
+            raise ValueError(f"precision must be one of {list(vit.PRECISIONS)}")
         # low-half weight passes of the V / output projections (vit.DEFAULT_WLO; "" = none): what puts every output within 1e-3
         self.wlo = kwargs.get("wlo", os.environ.get("MHMR_WLO"))
         vit.parse_wlo(vit.DEFAULT_WLO if self.wlo is None else self.wlo, 64)       # fail early on a malformed spec
@@ -275,7 +279,10 @@ class Model(nn.Module):
         self._ws = vit.WorkspaceCache()     # the workspaces of the most recent batch sizes
         self._person_cap = {}               # batch size -> person-row capacity of the next inference forward (fixed-capacity heads)
         self._streams = None                # side streams + events of the split backbone (_run_backbone)
-        self.split = kwargs.get("split")    # image blocks of the backbone on streams of their own (None: MHMR_SPLIT, default 2)
+        # workspaces, side streams / events and the capacity dict belong to the instance: concurrent forwards of ONE Model from two host
+        # threads would share them, so a forward holds this lock from start to end (one Model per thread for concurrency)
+        self._lock = threading.RLock()
+        self.split = kwargs.get("split")    # image blocks of the backbone on streams of their own (None: MHMR_SPLIT; 0 / unset = the automatic rule of _nsplit)
         for p in self.parameters():
             p.requires_grad_(False)
 
@@ -360,6 +367,11 @@ class Model(nn.Module):
         self._packed = P
         return P
 
+    @property
+    def packed_precision(self):
+        """The operand format the current pack runs ('f16', 'bf16' or 'f16x3'); None before the first forward / after a repack."""
+        return self._packed["precision"] if self._packed is not None else None
+
     def _nsplit(self, B):
         """Image blocks of the batch that run the backbone on streams of their own (``split=`` / MHMR_SPLIT; 0 or unset = automatic).
         Images never interact inside the backbone, so the blocks are independent launch sequences: the persistent GEMM / attention
@@ -368,8 +380,11 @@ class Model(nn.Module):
         4.2 rounds in the N = 1024 linears) +4.2 %, config 2 (ViT-S 672^2, 16 images) +5.2 %, config 3 +2 %; the headline (896^2, 32
         images: 8 exact rounds) +0.3 %, where it is left off so that every kernel has the chip to itself (per-kernel hipEvent / rocprofv3
         durations then mean what they say).  Automatic rule: two blocks when the batch is even, >= 8 images, and the narrowest block
-        linear is under six rounds.  Results do not depend on it (every kernel is batch-invariant: tests/test_gpu_fullsize.py,
-        test_backbone_image_blocks_on_side_streams_change_nothing)."""
+        linear is under six rounds.  Results do not depend on it as long as the blocks select the same kernels as the whole batch would
+        (every kernel is batch-invariant: tests/test_gpu_fullsize.py, test_backbone_image_blocks_on_side_streams_change_nothing); where the
+        block size changes the kernel choice or the row padding (ViT-S with one image per block: the 128x128 kernel and Tp a multiple of
+        128) outputs agree to rounding order, not bit for bit -- and since the automatic rule is the default for B >= 8, such a batch can
+        differ in the last bits from a run with split=1."""
         n = self.split if self.split is not None else int(os.environ.get("MHMR_SPLIT", "0"))
         if n <= 0:
             T = (self.img_size // PATCH) ** 2 + 1
@@ -451,7 +466,7 @@ class Model(nn.Module):
         (empty list if nobody is detected); ``is_training=True`` (needs ``idx``) -> dict of batched tensors.
         Extension used by ``distributed.forward_sharded``: ``return_image_index=True`` (inference only) -> (persons, image id [P]);
         ``return_batched=True`` (inference only) -> (dict of batched tensors [P, ...], image id [P]) instead of the per-person list."""
-        with torch.autocast("cuda", enabled=False):     # demo.forward_model wraps us in fp16 autocast (demo.py:117)
+        with self._lock, torch.autocast("cuda", enabled=False):     # demo.forward_model wraps us in fp16 autocast (demo.py:117)
             return self._forward(x.float().contiguous(), idx, det_thresh, nms_kernel_size, K, is_training,
                                  bool(kwargs.get("return_image_index", False)), bool(kwargs.get("return_batched", False)))
 

@@ -43,6 +43,60 @@ def hi_lo(w: torch.Tensor, tdt) -> torch.Tensor:
     return torch.cat([hi, lo], dim=1).contiguous()
 
 
+#: MFMA operand formats of ``Model(precision=...)``; "f16x3" = f16 operand PAIRS, three products per term, fp32 attention;
+#: "auto" = "f16" unless the checkpoint's attention logits are too steep for one 16-bit rounding per operand (``logit_gain``)
+PRECISIONS = ("f16", "fp16", "bf16", "f16x3", "auto")
+#: "auto" switches to "f16x3" when the steepest block's logit spread exceeds this (natural-log units; see ``logit_gain``)
+LOGIT_GAIN_LIMIT = 4.0
+
+
+def logit_gain(enc) -> list:
+    """Per block: the standard deviation, ACROSS THE KEYS of one query, of the pre-softmax attention logits (natural-log units) that the
+    block's weights produce from a LayerNorm output with unit-variance, independent channels -- rms over the heads.
+
+    Why this number: a 16-bit rounding of q, k (and of everything upstream of them) perturbs a logit by about 2^-12 times its own size,
+    i.e. the softmax weights by a RELATIVE 2^-12 x (logit spread) -- and every later block's logits see the earlier blocks' errors
+    through the same gain.  With norm1 = (gamma, beta):  q = Wq (gamma . xhat + beta) + bq ~ N(mu_q, S_q),  mu_q = Wq beta + bq,
+    S_q = Wq diag(gamma^2) Wq^T  (k likewise), so for one query the logit over the keys has variance
+        ( tr(S_q,h S_k,h) + mu_q,h^T S_k,h mu_q,h ) / 64        per head h (64 = head_dim; the scale 1/8 squared)
+    (the term that is constant over the keys shifts every logit of the row and cancels in the softmax).  Seeded DINOv2-style weights
+    (synthetic.make_state_dict): 1.7 for ViT-L, 0.6 for ViT-S.  synthetic.make_hostile(kind="weights") -- LayerNorm weights with
+    x10 ... x30 channels in front of q / k -- : ~10, where the fp32 network itself turns ONE 2^-12 input rounding into 2.5e-3 on an
+    output (tests/golden/vitl_672_hostile_w.npz: sens_*), and a single-rounding f16 pipeline ends 2-10x outside the 1e-3 contract."""
+    out = []
+    for b in enc.blocks:
+        Cd = b.attn.qkv.weight.shape[1]
+        W = b.attn.qkv.weight.detach().double().cpu()
+        bias = b.attn.qkv.bias.detach().double().cpu() if b.attn.qkv.bias is not None else torch.zeros(3 * Cd, dtype=torch.float64)
+        gam, beta = b.norm1.weight.detach().double().cpu(), b.norm1.bias.detach().double().cpu()
+        H = Cd // 64
+        Wq, Wk = (W[:Cd] * gam[None, :]).view(H, 64, Cd), (W[Cd:2 * Cd] * gam[None, :]).view(H, 64, Cd)
+        mu_q = (W[:Cd] @ beta + bias[:Cd]).view(H, 64)
+        Sq, Sk = Wq @ Wq.transpose(1, 2), Wk @ Wk.transpose(1, 2)                    # [H, 64, 64]
+        var = ((Sq * Sk).sum((1, 2)) + torch.einsum("hi,hij,hj->h", mu_q, Sk, mu_q)) / 64.0
+        out.append(float(var.mean().sqrt()))
+    return out
+
+
+def resolve_precision(enc, precision: str) -> str:
+    """'auto' -> 'f16' or 'f16x3' from the weights (``logit_gain``); anything else is returned as given ('fp16' = 'f16')."""
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be one of {list(PRECISIONS)}")
+    if precision == "fp16":
+        return "f16"
+    if precision != "auto":
+        return precision
+    return "f16x3" if max(logit_gain(enc)) > LOGIT_GAIN_LIMIT else "f16"
+
+
+def triple(w: torch.Tensor, tdt) -> torch.Tensor:
+    """fp32 [N, K] -> 16-bit [N, 3K] = [W_hi | W_lo | W_hi]: the weight operand of a three-product linear (GemmArgs::a_k, K = 3 a_k):
+    against the activation pair [A_hi | A_lo] the k ranges pair up as A_hi W_hi + A_hi W_lo + A_lo W_hi."""
+    hi = w.to(tdt)
+    lo = (w - hi.float()).to(tdt)
+    return torch.cat([hi, lo, hi], dim=1).contiguous()
+
+
 def fold_eligible(C: int, N: int) -> bool:
     """The LayerNorm fold (csrc/gemm256.hip, GemmArgs::pstats / rowstats) needs every block linear on the 256x256 kernel: embed_dim a
     multiple of 256 (ViT-B / ViT-L), and either the token-row map (N a multiple of 256) or, for any other N (1288^2: 8464), the rows
@@ -59,7 +113,10 @@ def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = N
     16-bit [N, K] linears (K contiguous = MFMA operand order), fp32 biases / LayerNorm / LayerScale, the pos-embed bicubically
     interpolated to the G x G grid on the host (``packing.interpolate_pos_embed``), the patch-embed weight flattened (c, py, px)
     and zero-padded to Kp = 640.  The returned dict owns every tensor the block descriptors point at (``keep``)."""
-    dt_id, tdt = packing.OP_DTYPES[precision]
+    requested = precision
+    precision = resolve_precision(enc, precision)
+    x3 = precision == "f16x3"
+    dt_id, tdt = packing.OP_DTYPES["f16" if x3 else precision]
     Cd, H, L = enc.embed_dim, enc.num_heads, len(enc.blocks)
     G = img_size // PATCH
     N, T = G * G, G * G + 1
@@ -72,12 +129,32 @@ def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = N
         return t.data_ptr()
 
     P = {"dt_id": dt_id, "tdt": tdt, "C": Cd, "H": H, "L": L, "G": G, "N": N, "T": T, "Kp": 640,
-         "S": img_size, "device": device}
+         "S": img_size, "device": device, "precision": precision, "precision_requested": requested, "x3": x3}
+    if requested == "auto" or x3:
+        P["logit_gain"] = logit_gain(enc)
     pos = torch.from_numpy(packing.interpolate_pos_embed(enc.pos_embed.detach().float().cpu().numpy(), G)).to(device)
     cls_pos0 = f32(enc.cls_token.reshape(-1)) + pos[0]
     pw = torch.zeros(Cd, P["Kp"], dtype=torch.float32, device=device)
     pw[:, :588] = f32(enc.patch_embed.proj.weight).reshape(Cd, 588)
     blocks = (_lib.VitBlock * L)()
+    if x3:
+        # every linear as three products over operand pairs; fp32 LayerNorm / GELU / attention (csrc/capi.hip vit_forward_x3)
+        tr = lambda t: triple(f32(t), tdt)
+        P["wlo"], P["fold"] = {}, False
+        for i, b in enumerate(enc.blocks):
+            blk = blocks[i]
+            blk.flags, blk.v_w2, blk.proj_w2, blk.qkv_colsum, blk.fc1_colsum = 0, None, None, None, None
+            blk.ln1_w, blk.ln1_b = k(f32(b.norm1.weight)), k(f32(b.norm1.bias))
+            blk.qkv_w, blk.qkv_b = k(tr(b.attn.qkv.weight)), k(f32(b.attn.qkv.bias))
+            blk.proj_w, blk.proj_b, blk.ls1 = k(tr(b.attn.proj.weight)), k(f32(b.attn.proj.bias)), k(f32(b.ls1.gamma))
+            blk.ln2_w, blk.ln2_b = k(f32(b.norm2.weight)), k(f32(b.norm2.bias))
+            blk.fc1_w, blk.fc1_b = k(tr(b.mlp.fc1.weight)), k(f32(b.mlp.fc1.bias))
+            blk.fc2_w, blk.fc2_b, blk.ls2 = k(tr(b.mlp.fc2.weight)), k(f32(b.mlp.fc2.bias)), k(f32(b.ls2.gamma))
+        P["vit"] = dict(blocks=blocks, patch_w=k(triple(pw, tdt)), patch_b=k(f32(enc.patch_embed.proj.bias)),
+                        cls_pos0=k(cls_pos0.contiguous()), pos=k(pos.contiguous()), norm_w=k(f32(enc.norm.weight)),
+                        norm_b=k(f32(enc.norm.bias)))
+        P["keep"] = keep
+        return P
     lo_passes = parse_wlo(DEFAULT_WLO if wlo is None else wlo, L)
     P["wlo"] = {i: sorted(v) for i, v in lo_passes.items()}
     # LayerNorm fold: norm2 -> fc1 in every block, norm1 -> qkv from block 1 on (block 0's norm1 follows the patch embedding, whose
@@ -135,7 +212,7 @@ def row_map(P: dict, B: int) -> bool:
     class rows through csrc/vit_cls.hip) when an image's patch rows are whole 256-row tiles of the 256x256 kernel."""
     import os
     T = P["T"]
-    return (os.environ.get("MHMR_ROWMAP", "1") != "0" and "MHMR_GEMM128" not in os.environ and P["C"] % 256 == 0 and (T - 1) % 256 == 0 and
+    return (not P.get("x3") and os.environ.get("MHMR_ROWMAP", "1") != "0" and "MHMR_GEMM128" not in os.environ and P["C"] % 256 == 0 and (T - 1) % 256 == 0 and
             B * roundup(T, 64) * P["C"] * 4 < 2 ** 32)
 
 
@@ -145,6 +222,8 @@ def padded_tokens(P: dict, B: int) -> int:
     (row_map), or embed_dim and B * Tp are multiples of 256; otherwise a multiple of 128, the row tile of the 128x128 kernel.
     896^2: 4160 instead of 4224 rows per image."""
     import os
+    if P.get("x3"):
+        return roundup(P["T"], 256 if P["C"] % 256 == 0 else 128)      # all rows through every linear: whole tiles for every batch size
     if P.get("fold") and (P["T"] - 1) % 256:
         return roundup(P["T"], 256)        # folded LayerNorms without the row map: whole 256-row tiles of all rows, for every batch size
     t64, t128 = roundup(P["T"], 64), roundup(P["T"], 128)
@@ -190,11 +269,16 @@ class WorkspaceCache:
                                  "build the model with lnfold=False for such batches")
         v = P["vit"]
         parts = []
+        x3 = bool(P.get("x3"))
         for i in range(nsplit):
             Mp = roundup(Bh * N, 128)
-            b = dict(a_patch=z(Mp, P["Kp"]), resid=z(Bh * Tp, Cd, dtype=torch.float32), xn=z(Bh * Tp, Cd), qk=z(Bh * Tp, 2 * Cd),
-                     vt=z(Bh * H * 64, Tp), att=z(Bh * Tp, Cd), hid=z(Bh * Tp, 4 * Cd),
-                     attn_flags=z(_lib.lib().mhmr_attention_flag_count(Bh, Tp, H), dtype=torch.int32))
+            if x3:       # operand pairs [hi | lo] and the two fp32 intermediates (include/mhmr.h, mhmr_vit_desc.x3)
+                b = dict(a_patch=z(Mp, 2 * P["Kp"]), resid=z(Bh * Tp, Cd, dtype=torch.float32), xn=z(Bh * Tp, 2 * Cd), att=z(Bh * Tp, 2 * Cd),
+                         hid=z(Bh * Tp, 8 * Cd), qkv32=z(Bh * Tp, 3 * Cd, dtype=torch.float32), hid32=z(Bh * Tp, 4 * Cd, dtype=torch.float32))
+            else:
+                b = dict(a_patch=z(Mp, P["Kp"]), resid=z(Bh * Tp, Cd, dtype=torch.float32), xn=z(Bh * Tp, Cd), qk=z(Bh * Tp, 2 * Cd),
+                         vt=z(Bh * H * 64, Tp), att=z(Bh * Tp, Cd), hid=z(Bh * Tp, 4 * Cd),
+                         attn_flags=z(_lib.lib().mhmr_attention_flag_count(Bh, Tp, H), dtype=torch.int32))
             if P.get("fold"):
                 b.update(pstats=z(Bh * Tp, Cd // 64, 2, dtype=torch.float32), rowstats=z(Bh * Tp, 2, dtype=torch.float32))
             d = _lib.VitDesc()
@@ -203,8 +287,9 @@ class WorkspaceCache:
             d.patch_w, d.patch_b, d.cls_pos0, d.pos = v["patch_w"], v["patch_b"], v["cls_pos0"], v["pos"]
             d.blocks = C.cast(v["blocks"], C.POINTER(_lib.VitBlock))
             d.norm_w, d.norm_b = v["norm_w"], v["norm_b"]
-            for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid", "attn_flags"):
-                setattr(d, n, b[n].data_ptr())
+            for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid", "attn_flags", "qkv32", "hid32"):
+                setattr(d, n, b[n].data_ptr() if n in b else None)
+            d.x3 = 1 if x3 else 0
             d.pstats = b["pstats"].data_ptr() if P.get("fold") else None
             d.rowstats = b["rowstats"].data_ptr() if P.get("fold") else None
             parts.append(dict(desc=d, B=Bh, img0=i * Bh, bufs=b))

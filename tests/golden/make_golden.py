@@ -36,6 +36,8 @@ CASES = {
     # ``vstride`` keeps the files small: v3d / v2d are stored for every vstride-th vertex, everything else in full.
     "vits_672_full": dict(backbone="dinov2_vits14", img_size=672, depth_override=None, batch=2, persons=[8, 5], seed=21, vstride=4),
     "vitl_672_full": dict(backbone="dinov2_vitl14", img_size=672, depth_override=None, batch=1, persons=[8], seed=22, vstride=4),
+    # multiHMR_672_B: the released ViT-B size at full depth and resolution (README.md:90; no BASELINE.json config of its own)
+    "vitb_672_full": dict(backbone="dinov2_vitb14", img_size=672, depth_override=None, batch=2, persons=[6, 9], seed=25, vstride=4),
     "vitl_896_full": dict(backbone="dinov2_vitl14", img_size=896, depth_override=None, batch=1, persons=[8], seed=23, vstride=4),
     "vitl_1288_full": dict(backbone="dinov2_vitl14", img_size=1288, depth_override=None, batch=1, persons=[20], seed=24, vstride=8),
     # constructor arguments off their defaults (model.py:39-40): 8 frequency bands up to resolution 32 -> 51 camera channels

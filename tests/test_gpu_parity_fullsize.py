@@ -5,8 +5,13 @@ model.py run verbatim on CPU fp32 (tests/golden/make_golden.py, cases *_full: fu
   vitl_672_full   multiHMR_672_L   672^2,  T = 2305, ViT-L/14 24 blocks, 8 persons            (config 3)
   vitl_896_full   multiHMR_896_L   896^2,  T = 4097, ViT-L/14 24 blocks, 8 persons            (config 4, the benchmark)
   vitl_1288_full  multiHMR_1288_L  1288^2, T = 8465, ViT-L/14 24 blocks, 20 persons           (config 5)
+  vitb_672_full   multiHMR_672_B   672^2,  T = 2305, ViT-B/14 12 blocks, 6 + 9 persons        (released size without a BASELINE config)
   vitl_672_hostile_w / _m   config 3's shape with hostile weight statistics (synthetic.make_hostile: LayerScale over three decades,
-                  LayerNorm weights with x10 ... x30 channels, large biases / token rows ~2 sigma away from zero through the depth)
+                  LayerNorm weights with x10 ... x30 channels, large biases / token rows ~2 sigma away from zero through the depth).
+                  hostile_w is what precision="auto" (the product default) exists for: its attention logits are steep (vit.logit_gain
+                  ~20 against 1.5), the pack selects the f16x3 mode and the case is held to the plain 1e-3 on every key, like every
+                  other case -- no sensitivity-scaled slack anywhere in this file.  The same weights with the precision forced to f16 /
+                  bf16 are measured beside it (reported; 2-10x outside the contract, as the network's own sensitivity predicts).
 
 Every tensor of the output dict must be within the tolerances of tests/parity.py (1e-3 relative L2 for f16 operands, the product
 precision and what bench.py reports -- every key, no exceptions: the V / attention-output projections of blocks 0..11 carry the low
@@ -42,8 +47,13 @@ def _report(name, precision, entry):
         json.dump(data, f, indent=1, sort_keys=True)
 
 
-@pytest.mark.parametrize("precision", ["f16", "bf16"])
-@pytest.mark.parametrize("name", ["vits_672_full", "vitl_672_full", "vitl_896_full", "vitl_1288_full", "vitl_672_hostile_w", "vitl_672_hostile_m"])
+BASE_CASES = ["vits_672_full", "vitb_672_full", "vitl_672_full", "vitl_896_full", "vitl_1288_full", "vitl_672_hostile_m"]
+#: (golden, precision).  "auto" is the product default: plain f16 for every case but hostile_w, whose weights select f16x3 at pack time
+PARAMS = ([(n, p) for n in BASE_CASES for p in ("f16", "bf16")] +
+          [("vitl_672_hostile_w", "auto"), ("vitl_672_hostile_w", "f16"), ("vitl_672_hostile_w", "bf16"), ("vitl_896_full", "auto")])
+
+
+@pytest.mark.parametrize("name,precision", PARAMS)
 def test_full_size_forward_matches_reference_golden(name, precision, smplx_data, mean_params):
     cfg = make_golden.CASES[name]
     gold = np.load(os.path.join(GOLD, name + ".npz"))
@@ -53,6 +63,10 @@ def test_full_size_forward_matches_reference_golden(name, precision, smplx_data,
     model = model.to("cuda:0").eval()
     x, K, idx = make_golden.case_inputs(cfg)
     z = model.backbone_features(x.cuda()).cpu()
+    packed = model.packed_precision                      # what "auto" resolved to
+    hostile_w = name == "vitl_672_hostile_w"
+    if precision == "auto":
+        assert packed == ("f16x3" if hostile_w else "f16"), (packed, model._packed.get("logit_gain"))
     e_bb = rel(z[:, :: max(1, z.shape[1] // 64)].numpy(), gold["backbone"])
     out = model(x.cuda(), idx=tuple(i.cuda() for i in idx), K=K.cuda(), is_training=True)
     got = {k: out[k].cpu() for k in CHECKED + ["rotvec"]}
@@ -66,29 +80,36 @@ def test_full_size_forward_matches_reference_golden(name, precision, smplx_data,
     finite = all(bool(torch.isfinite(v).all()) for v in got.values())
     # the same keys in the max norm (rotations through the matrices they encode)
     merrs = {k: maxrel(got[k].numpy(), gold[k]) for k in CHECKED}
-    _report(name, precision, {"tolerance": TOL[precision], "wlo": model._packed["wlo"], "lnfold": bool(model._packed["fold"]),
+    tolkey = "bf16" if precision == "bf16" else "f16"           # f16, auto and f16x3 answer to the 1e-3 contract
+    sens = {k[5:]: float(gold[k]) for k in gold.files if k.startswith("sens_")}
+    _report(name, precision, {"tolerance": TOL[tolkey], "packed_precision": packed, "wlo": model._packed["wlo"], "lnfold": bool(model._packed["fold"]),
+                              "logit_gain_max": max(model._packed["logit_gain"]) if "logit_gain" in model._packed else None,
                               "backbone_rel_l2": e_bb, "max_vertex_error_mm": vmax_mm,
                               "worst_rel_l2": max(errs.values()), "rel_l2": errs, "finite": finite,
-                              "max_norm_tolerance": MAXTOL[precision], "worst_max_norm": max(merrs.values()), "max_norm": merrs,
-                              "network_sensitivity": {k[5:]: float(gold[k]) for k in gold.files if k.startswith("sens_")},
+                              "max_norm_tolerance": MAXTOL[tolkey], "worst_max_norm": max(merrs.values()), "max_norm": merrs,
+                              "network_sensitivity": sens,
                               "tokens": int(cfg["img_size"] // 14) ** 2 + 1, "persons": int(sum(cfg["persons"]))})
-    print(f"\n[parity {name} {precision}] backbone {e_bb:.2e}; max vertex error {vmax_mm:.3f} mm; " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
+    print(f"\n[parity {name} {precision} -> {packed}] backbone {e_bb:.2e}; max vertex error {vmax_mm:.3f} mm; " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
     assert finite
-    # Hostile weight statistics: the golden also holds the NETWORK's sensitivity sens_<key> = relative change of that output of the
-    # fp32 reference when the image is rounded once to f16 (a 2^-12 relative perturbation; make_golden.py).  An implementation with
-    # 16-bit matrix operands makes ~10^2 roundings of that size; where ONE already costs more than a sixth of the contract the bound
-    # is 6 x sens instead of 1e-3 (measured: 4 x on `offset`) (vitl_672_hostile_w: LayerNorm weights with x30 channels in front of q / k make the softmax nearly
-    # an arg-max -- `offset` moves by 2.5e-3 from that single rounding; vitl_672_hostile_m keeps the plain 1e-3).
-    # (one slack per CASE, from its most sensitive output: a single perturbation sample per key is too noisy a yardstick for that key --
-    # `dist` moved by 1.9e-4 in the sample and is 1.5e-3 off on the GPU, `offset` 2.5e-3 and 1.0e-2)
-    case_slack = max([1.0] + [6.0 * float(gold[k]) / 1e-3 for k in gold.files if k.startswith("sens_")])
-    slack = {k: case_slack for k in errs}
+    if hostile_w and precision != "auto":
+        # Hostile weight statistics with the precision FORCED to a single 16-bit rounding per operand: measured and reported, not held to
+        # the contract.  The golden stores the NETWORK's own sensitivity sens_<key> (the fp32 reference's response to ONE f16 rounding
+        # of its input image: `offset` 2.5e-3); a pipeline that makes ~10^2 such roundings lands at 2-10x the contract here (round 4:
+        # offset 9.8e-3, rotmat 2.8e-3, v3d 1.8e-3).  These weights are what precision="auto" exists for: the case above this one
+        # packs them as f16x3 and is held to the plain 1e-3 on EVERY key, max norm included.  What is asserted here is only that the
+        # single-rounding result is the well-behaved one that analysis predicts (no blow-up), so that a regression still shows.
+        for k, v in errs.items():
+            assert v < (3e-2 if precision == "f16" else 3e-1), (name, k, v)
+        return
+    # the contract, per key, no slack: 1e-3 relative L2 (bf16: its own, looser bound) ...
     for k, v in errs.items():
-        assert v < TOL[precision] * slack[k], (name, k, v, TOL[precision] * slack[k])
-    assert e_bb < 2 * TOL[precision] * max(slack.values()), e_bb            # not a north-star output; informational bound
-    for k, v in merrs.items():           # max norm: where the contract itself applies (reported, not gated, for sensitivity-scaled keys)
-        if slack[k] == 1.0:
-            assert v < MAXTOL[precision], (name, "max-norm", k, v)
+        assert v < TOL[tolkey], (name, precision, k, v, TOL[tolkey])
+    assert e_bb < 2 * TOL[tolkey], e_bb                  # not a north-star output; informational bound
+    # ... and the max-norm gate on every key
+    for k, v in merrs.items():
+        assert v < MAXTOL[tolkey], (name, "max-norm", k, v)
+    if packed == "f16x3":
+        assert e_bb < 1e-4 and max(errs.values()) < 3e-4, (e_bb, errs)      # the pair mode sits at fp32 accuracy, far inside the contract
 
 
 def test_four_image_batch_uses_64_row_padding_and_matches_golden(smplx_data, mean_params):

@@ -1,0 +1,182 @@
+"""-m gpu: the "f16x3" precision mode (include/mhmr.h mhmr_vit_desc.x3) -- operand pairs, three 16-bit products per
+term in every backbone linear, fp32 attention -- and the pack-time rule that selects it (vit.logit_gain).  Each new kernel / kernel
+mode against fp64 torch through the C ABI, then the whole backbone against the CPU oracle at ~fp32 accuracy."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import make_golden  # noqa: E402
+import parity  # noqa: E402
+import synthetic  # noqa: E402
+from multi_hmr_amd import Model, _lib, vit  # noqa: E402
+from parity import CHECKED, rel  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def L():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _lib.lib()
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def trel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def pair(x, tdt=torch.float16):
+    hi = x.to(tdt)
+    return torch.cat([hi, (x - hi.float()).to(tdt)], dim=1).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (128, 128, 128), (512, 256, 1024), (256, 1152, 384), (256, 256, 4096)])
+@pytest.mark.parametrize("epi", ["f32", "resid"])
+def test_three_product_linear(L, M, N, K, epi):
+    """A = [A_hi | A_lo], W = [W_hi | W_lo | W_hi], K = 3 a_k: one accumulator chain computes A_hi W_hi + A_hi W_lo + A_lo W_hi -- against
+    fp64 on the UNROUNDED operands the error is ~2^-21, three orders below a single f16 pass (both GEMM kernels: 256x256 and 128x128)."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A32 = torch.randn(M, K, generator=g).to(dev())
+    A32[:, 3] *= 40.0                                                           # a hot channel, as behind a x30 LayerNorm weight
+    W32 = (torch.randn(N, K, generator=g) * 0.03).to(dev())
+    bias = torch.randn(N, generator=g).to(dev())
+    A2, W3 = pair(A32), vit.triple(W32, torch.float16)
+    assert A2.shape == (M, 2 * K) and W3.shape == (N, 3 * K)
+    exact = A32.double() @ W32.double().T
+    if epi == "f32":
+        out = torch.zeros(M, N, device=dev())
+        _lib.check(L.mhmr_gemm16_ex(A2.data_ptr(), 2 * K, W3.data_ptr(), 3 * K, M, N, 3 * K, bias.data_ptr(), None, out.data_ptr(), N, None, 0, 128, 1,
+                                    M, _lib.EPI_F32, _lib.DT_F16, 0, 0, K, stream()), "gemm x3")
+        got = out.double() - bias.double()
+    else:
+        gamma = (0.5 + torch.rand(N, generator=g)).to(dev())
+        r0 = torch.randn(M, N, generator=g).to(dev())
+        out = r0.clone()
+        _lib.check(L.mhmr_gemm16_ex(A2.data_ptr(), 2 * K, W3.data_ptr(), 3 * K, M, N, 3 * K, bias.data_ptr(), gamma.data_ptr(), out.data_ptr(), N, None,
+                                    0, 128, 1, M, _lib.EPI_RESID, _lib.DT_F16, 0, 0, K, stream()), "gemm x3 resid")
+        got = (out.double() - r0.double()) / gamma.double() - bias.double()
+    one = torch.zeros(M, N, device=dev())
+    _lib.check(L.mhmr_gemm16(A2[:, :K].contiguous().data_ptr(), K, W3[:, :K].contiguous().data_ptr(), K, M, N, K, None, None, one.data_ptr(), N, None,
+                             0, 128, 1, M, _lib.EPI_F32, _lib.DT_F16, stream()), "gemm hi")
+    e3, e1 = trel(got, exact), trel(one, exact)
+    assert e1 > 1e-4, e1                          # one f16 rounding per operand
+    assert e3 < (5e-6 if epi == "f32" else 2e-5), (e3, e1)     # (the residual form is read back through out - r0: fp32 cancellation)
+    assert e3 < e1 / 50
+
+
+@pytest.mark.parametrize("B,T,Tp,H", [(2, 257, 384, 6), (1, 2305, 2560, 16), (3, 197, 256, 12), (1, 64, 64, 1), (1, 65, 128, 2)])
+def test_attention_f32_against_fp64(L, B, T, Tp, H):
+    """softmax(Q K^T / 8) V in exact fp32 products, the output as an f16 pair; steep logits (spread ~12) like a hostile checkpoint's."""
+    C = 64 * H
+    g = torch.Generator(device="cpu").manual_seed(T + H)
+    qkv = torch.randn(B, Tp, 3 * C, generator=g)
+    qkv[..., :C] *= 3.5                                      # logit std over the keys ~ 3.5 * 8 / 8 * ... : an almost arg-max softmax
+    qkv[:, T:] = 7.0                                         # padding rows hold finite garbage; their keys must be masked
+    qkv = qkv.to(dev()).contiguous()
+    out = torch.full((B * Tp, 2 * C), float("nan"), dtype=torch.float16, device=dev())      # every row must be WRITTEN
+    _lib.check(L.mhmr_attention_f32(qkv.data_ptr(), out.data_ptr(), B, T, Tp, C, H, _lib.DT_F16, stream()), "attention_f32")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out.float()).all())
+    got = (out[:, :C].double() + out[:, C:].double()).view(B, Tp, H, 64)
+    q, k, v = (qkv[..., i * C:(i + 1) * C].double().view(B, Tp, H, 64) for i in range(3))
+    s = torch.einsum("bqhd,bkhd->bhqk", q[:, :T], k[:, :T]) * 0.125
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, dim=-1), v[:, :T])
+    assert float(s.std(dim=-1).mean()) > 3.0
+    e = trel(got[:, :T], ref)
+    assert e < 5e-6, e
+    # rows of all-padding 16-query blocks are zeros; the hi half alone is an f16 rounding of the result
+    q_blocks = (T + 15) // 16 * 16
+    assert float(got[:, q_blocks:].abs().max()) == 0.0 if q_blocks < Tp else True
+    assert trel(out[:, :C].double().view(B, Tp, H, 64)[:, :T], ref) > 1e-4
+
+
+@pytest.mark.parametrize("C", [384, 768, 1024])
+def test_layernorm_and_gelu_pairs(L, C):
+    g = torch.Generator(device="cpu").manual_seed(C)
+    rows = 300
+    x = (torch.randn(rows, C, generator=g) * 3 + 1.5).to(dev())
+    w, b = (torch.exp(0.5 * torch.randn(C, generator=g))).to(dev()), torch.randn(C, generator=g).to(dev())
+    w[5] *= 30.0
+    out = torch.zeros(rows, 2 * C, dtype=torch.float16, device=dev())
+    _lib.check(L.mhmr_layernorm16_pair(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), rows, C, 1e-6, _lib.DT_F16, stream()), "ln pair")
+    ref = torch.nn.functional.layer_norm(x.double(), (C,), w.double(), b.double(), 1e-6)
+    got = out[:, :C].double() + out[:, C:].double()
+    assert trel(got, ref) < 2e-6 and trel(out[:, :C].double(), ref) > 1e-4
+    h32 = (torch.randn(rows, 4 * C, generator=g) * 2).to(dev())
+    o2 = torch.zeros(rows, 8 * C, dtype=torch.float16, device=dev())
+    _lib.check(L.mhmr_gelu16_pair(h32.data_ptr(), o2.data_ptr(), rows, 4 * C, _lib.DT_F16, stream()), "gelu pair")
+    ref2 = torch.nn.functional.gelu(h32.double())
+    got2 = o2[:, :4 * C].double() + o2[:, 4 * C:].double()
+    assert trel(got2, ref2) < 2e-6, trel(got2, ref2)
+
+
+def _build(cfg, smplx_data, mean_params, precision, sd=None):
+    sd = make_golden.case_state_dict(cfg) if sd is None else sd
+    m = Model(backbone=cfg["backbone"], img_size=cfg["img_size"], smplx_data=smplx_data, mean_params=mean_params,
+              backbone_depth=cfg["depth_override"], precision=precision, **cfg.get("model_kwargs", {}))
+    m.load_state_dict(sd, strict=True)
+    return m.to("cuda:0").eval()
+
+
+@pytest.mark.parametrize("name", ["vits_224_train", "vitb_224_train", "vitl_224_train"])
+def test_x3_forward_matches_reference_golden_at_fp32_accuracy(name, smplx_data, mean_params):
+    """precision='f16x3' on the small goldens (ViT-S on the 128x128 kernel, ViT-B / ViT-L on the 256x256 kernel): the backbone features
+    within 3e-5 of the reference's fp32 run (f16: 3-6e-4), every output within a tenth of the 1e-3 contract."""
+    cfg = make_golden.CASES[name]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    model = _build(cfg, smplx_data, mean_params, "f16x3")
+    x, K, idx = make_golden.case_inputs(cfg)
+    z = model.backbone_features(x.cuda()).cpu()
+    assert model.packed_precision == "f16x3" and model._packed["x3"]
+    e_bb = rel(z[:, :: max(1, z.shape[1] // 64)].numpy(), gold["backbone"])
+    out = model(x.cuda(), idx=tuple(i.cuda() for i in idx), K=K.cuda(), is_training=True)
+    errs = {k: rel(out[k].cpu().numpy(), gold[k]) for k in CHECKED}
+    print(f"\n[x3 {name}] backbone {e_bb:.2e} " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
+    assert e_bb < 3e-5, e_bb
+    for k, v in errs.items():
+        assert v < 1e-4, (k, v)
+    # batch invariance and repeatability of the mode (fixed accumulation orders everywhere)
+    z2 = model.backbone_features(x.cuda()).cpu()
+    assert torch.equal(z, z2)
+
+
+def test_auto_precision_follows_the_weights(smplx_data, mean_params):
+    """'auto' (the default): seeded DINOv2-style weights pack as plain f16 exactly as precision='f16' does; weights with x10 ... x30
+    LayerNorm channels in front of q / k (synthetic.make_hostile) pack as f16x3."""
+    cfg = dict(make_golden.CASES["vitl_224_train"])
+    sd = make_golden.case_state_dict(cfg)
+    x, K, idx = make_golden.case_inputs(cfg)
+    auto, f16 = _build(cfg, smplx_data, mean_params, "auto", sd), _build(cfg, smplx_data, mean_params, "f16", sd)
+    za, zf = auto.backbone_features(x.cuda()).clone(), f16.backbone_features(x.cuda()).clone()
+    assert auto.packed_precision == "f16" and not auto._packed["x3"] and max(auto._packed["logit_gain"]) < 2.0
+    assert torch.equal(za, zf)
+    assert auto._packed["wlo"] == f16._packed["wlo"] and auto._packed["fold"] == f16._packed["fold"]
+    sdh = synthetic.make_hostile({k: v.clone() for k, v in sd.items()}, "weights", seed=3)
+    hostile = _build(cfg, smplx_data, mean_params, "auto", sdh)
+    hostile.backbone_features(x.cuda())
+    assert hostile.packed_precision == "f16x3" and max(hostile._packed["logit_gain"]) > vit.LOGIT_GAIN_LIMIT
+    # and the hostile weights through the oracle: the pair mode is at fp32 accuracy where plain f16 is not
+    from oracle.multihmr_ref import OracleModel
+    ref = OracleModel(sdh, smplx_data, backbone=cfg["backbone"], img_size=cfg["img_size"], depth_override=cfg["depth_override"])
+    out_r = ref.forward(x, idx=idx, K=K, is_training=True)
+    out_h = hostile(x.cuda(), idx=tuple(i.cuda() for i in idx), K=K.cuda(), is_training=True)
+    plain = _build(cfg, smplx_data, mean_params, "f16", sdh)
+    out_p = plain(x.cuda(), idx=tuple(i.cuda() for i in idx), K=K.cuda(), is_training=True)
+    eh = {k: rel(out_h[k].cpu().numpy(), out_r[k].numpy()) for k in CHECKED}
+    ep = {k: rel(out_p[k].cpu().numpy(), out_r[k].numpy()) for k in CHECKED}
+    print("\n[hostile 224] x3 " + " ".join(f"{k}={v:.1e}" for k, v in eh.items()) + "\n              f16 " + " ".join(f"{k}={v:.1e}" for k, v in ep.items()))
+    for k in CHECKED:
+        assert eh[k] < 2e-4, (k, eh[k])
+    assert max(ep.values()) > 4 * max(eh.values())

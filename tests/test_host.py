@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_builds_loads_and_exports_every_declared_symbol():
     _lib.build()
     lib = _lib.lib()
-    assert lib.mhmr_version() == _lib.VERSION == 103
+    assert lib.mhmr_version() == _lib.VERSION == 104
     header = open(os.path.join(ROOT, "include", "mhmr.h")).read()
     declared = set(re.findall(r"\b(?:int|const char\*)\s+(mhmr_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
@@ -295,3 +295,59 @@ def test_image_block_rule_of_the_backbone(smplx_data, mean_params):
     assert m._nsplit(2) == 1 and m._nsplit(7) == 1 and m._nsplit(8) == 2
     assert mk("dinov2_vitl14", 224, split=1)._nsplit(8) == 1 and mk("dinov2_vitl14", 224, split=4)._nsplit(8) == 4
     assert mk("dinov2_vitl14", 224, split=4)._nsplit(6) == 3 and mk("dinov2_vitl14", 224, split=2)._nsplit(5) == 1
+
+
+def test_logit_gain_statistic_and_the_auto_precision_rule():
+    """vit.logit_gain: the spread of a block's pre-softmax logits over the keys of one query, predicted from the weights alone --
+    checked here against the EMPIRICAL spread of the same block on unit-variance LayerNorm inputs; and the rule built on it."""
+    from multi_hmr_amd import vit
+    from multi_hmr_amd.model import Dinov2Backbone
+    for hostile in (False, True):
+        sd = synthetic.make_state_dict("dinov2_vits14", 224, seed=5, depth_override=2)
+        if hostile:
+            synthetic.make_hostile(sd, "weights", seed=5)
+        bb = Dinov2Backbone("dinov2_vits14", pretrained=False, depth_override=2)
+        bb.load_state_dict({k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}, strict=True)
+        enc = bb.encoder
+        gains = vit.logit_gain(enc)
+        assert len(gains) == 2
+        g = torch.Generator().manual_seed(0)
+        blk, C, H = enc.blocks[0], 384, 6
+        xh = torch.randn(4096, C, generator=g, dtype=torch.float64)                        # the LayerNorm's normalised rows
+        y = xh * blk.norm1.weight.double() + blk.norm1.bias.double()
+        qkv = y @ blk.attn.qkv.weight.double().T + blk.attn.qkv.bias.double()
+        q, k = qkv[:64, :C].view(64, H, 64), qkv[:, C:2 * C].view(-1, H, 64)
+        logits = torch.einsum("qhd,khd->hqk", q, k) * 0.125
+        emp = float(logits.detach().var(dim=-1).mean(dim=-1).mean().sqrt())                          # rms over heads and queries of the per-row std
+        assert abs(gains[0] - emp) / emp < 0.12, (hostile, gains[0], emp)
+        assert (gains[0] > vit.LOGIT_GAIN_LIMIT) == hostile, gains
+        assert vit.resolve_precision(enc, "auto") == ("f16x3" if hostile else "f16")
+        assert vit.resolve_precision(enc, "bf16") == "bf16" and vit.resolve_precision(enc, "fp16") == "f16"
+    with pytest.raises(ValueError):
+        vit.resolve_precision(enc, "fp8")
+
+
+def test_three_product_operands_reconstruct_the_fp32_product():
+    """vit.triple against an activation pair: hi.hi + hi.lo + lo.hi (what the k ranges of GemmArgs::a_k with K = 3 a_k pair up) is the
+    fp32 product to ~2^-21; and the f16x3 pack lays every backbone linear out that way."""
+    from multi_hmr_amd import vit
+    g = torch.Generator().manual_seed(0)
+    W, A = torch.randn(64, 128, generator=g) * 0.03, torch.randn(32, 128, generator=g) * 5
+    W3 = vit.triple(W, torch.float16)
+    ah = A.half()
+    A2 = torch.cat([ah, (A - ah.float()).half()], 1)
+    K = 128
+    Amap = torch.cat([A2[:, :K], A2[:, :K], A2[:, K:]], 1)                                  # the kernel's k-tile map: hi, hi, lo
+    got = Amap.double() @ W3.double().T
+    exact = A.double() @ W.double().T
+    one = ah.double() @ W.half().double().T
+    e3 = float((got - exact).norm() / exact.norm())
+    e1 = float((one - exact).norm() / exact.norm())
+    assert e3 < 1e-6 and e1 > 2e-4 and W3.shape == (64, 384)
+    from multi_hmr_amd.model import Dinov2Backbone
+    bb = Dinov2Backbone("dinov2_vits14", pretrained=False, depth_override=1)
+    P = vit.pack_encoder(bb.encoder, 224, "f16x3", "cpu")
+    assert P["x3"] and P["precision"] == "f16x3" and not P["fold"] and P["wlo"] == {}
+    assert vit.padded_tokens(P, 3) == 384 and not vit.row_map(P, 4)                         # T = 257 -> whole 128-row tiles (C = 384)
+    shapes = sorted(tuple(t.shape) for t in P["keep"] if t.dtype == torch.float16)
+    assert (384, 3 * 640) in shapes and (3 * 384, 3 * 384) in shapes and (384, 12 * 384) in shapes and (4 * 384, 3 * 384) in shapes
