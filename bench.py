@@ -61,6 +61,15 @@ def lbs_bytes(P, nb=10):
     return const + P * (764 + 10475 * 3 * 4 + 10475 * 2 * 4 + 127 * 5 * 4)
 
 
+def lbs_bytes_shipped(P, Vp=10752, V=10475):
+    """HBM bytes the SHIPPED layer has to move per launch: the f16 basis as packed (162 KiB per 48-vertex tile: high halves for the pose
+    correctives, an f16 pair for the last 64 k) + the dense f16-pair skin weights (12 KiB per tile) + the fp32 template once, and per
+    person the same inputs / outputs as lbs_bytes (the operand fragments the pose role leaves are L2-resident, not counted)."""
+    tiles = Vp // 48
+    const = tiles * (165888 + 12288) + 3 * Vp * 4
+    return const + P * (764 + V * 3 * 4 + V * 2 * 4 + 127 * 5 * 4)
+
+
 def lib_sha16():
     with open(_lib.LIB_PATH, "rb") as f:
         return hashlib.sha256(f.read()).hexdigest()[:16]
@@ -492,9 +501,11 @@ def lbs_bench(model, dev, P=160, iters=20):
     bufs = [f((P + 15) // 16 * 16, lb["Kb"]), f((P + 15) // 16 * 16, 768), f(P, 24), f(P, V, 3), f(P, V, 2), f(P, 127, 3), f(P, 127, 2), f(P, 3)]
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    def run():
-        _lib.check(L.mhmr_lbs_forward(C.byref(cs), pose.data_ptr(), shape.data_ptr(), expr.data_ptr(), loc.data_ptr(), dist.data_ptr(),
-                                      K.data_ptr(), det_b.data_ptr(), P, *[b.data_ptr() for b in bufs], stream), "lbs")
+    sync = Pk["lbs_sync"]
+
+    def run():      # the entry Model.forward calls: one fused launch (pose role + vertex role)
+        _lib.check(L.mhmr_lbs_forward_fused(C.byref(cs), pose.data_ptr(), shape.data_ptr(), expr.data_ptr(), loc.data_ptr(), dist.data_ptr(),
+                                            K.data_ptr(), det_b.data_ptr(), P, *[b.data_ptr() for b in bufs], sync.data_ptr(), stream), "lbs")
     for _ in range(3):
         run()
     torch.cuda.synchronize(dev)
@@ -507,12 +518,20 @@ def lbs_bench(model, dev, P=160, iters=20):
     n, ms, _ = prof_collect()
     avg = ms / max(n, 1) * 1e-3
     gbs = lbs_bytes(P) / avg / 1e9 if avg > 0 else 0.0
+    gbs_s = lbs_bytes_shipped(P) / avg / 1e9 if avg > 0 else 0.0
     pmc = pmc_summary()
+    kern = (pmc or {}).get("lbs_fused_kernel") or (pmc or {}).get("lbs_vertex_kernel") or {}
     return {"persons": P, "ms_per_person": round(1e3 * wall / P, 6), "layer_ms": round(1e3 * wall, 4),
-            "roofline": {"kernel": "lbs_vertex_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "lbs_fused_kernel (ONE launch: pose role = leading workgroups, vertex role behind per-person ready flags)",
+                         "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": round(gbs / PEAK_HBM_GBS, 4),
-                         "traffic": (pmc or {}).get("lbs_vertex_kernel", {}).get("total_bytes_per_launch") if P == 160 else None,
-                         "algorithmic_bytes": lbs_bytes(P), "avg_launch_ms": round(avg * 1e3, 4)}}
+                         "traffic": kern.get("total_bytes_per_launch") if P == 160 else None,
+                         "traffic_source": ("profiles/" + pmc["_file"]) if (pmc and P == 160 and kern) else None,
+                         "algorithmic_bytes": lbs_bytes(P), "avg_launch_ms": round(avg * 1e3, 4),
+                         # SURVEY 8(d)'s figure prices the reference's fp32 constants (66.4 MB); the shipped layer keeps them as f16
+                         # (40 MB): against the bytes it actually has to move the same launch reads as
+                         "shipped_bytes": lbs_bytes_shipped(P), "achieved_shipped": round(gbs_s, 1), "frac_shipped": round(gbs_s / PEAK_HBM_GBS, 4),
+                         "note": "avg_launch_ms is the whole fused launch (pose role included): the layer IS this launch"}}
 
 
 def cpu_model_name():

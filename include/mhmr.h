@@ -339,6 +339,17 @@ int mhmr_lbs_forward(const mhmr_lbs_consts* c, const float* rotvec, const float*
                      float* ws_A, float* ws_xf, float* v3d, float* v2d, float* j3d, float* j2d, float* transl,
                      void* stream);
 
+/* The same layer as ONE launch (round 5): the pose work (Rodrigues, joint regression, kinematic chain: a 10 us latency chain) runs as the
+ * leading workgroups of the vertex grid while the other workgroups already stream the blend basis; per-person ready flags in ws_sync
+ * order the two.  ws_sync: [1 + roundup(P,16)] ints, ZERO before the first call; every call leaves it zero again (so a workspace can be
+ * allocated and cleared once and reused by every later call on the same stream; two calls in flight need two workspaces).  Results are
+ * bit-identical to mhmr_lbs_forward.  Falls back to mhmr_lbs_forward's two launches (ws_sync untouched) for P > 160 or when the device
+ * has fewer CUs than the fused grid has workgroups (224 + 5 vertex tiles + roundup(P,16) / 12 pose workgroups). */
+int mhmr_lbs_forward_fused(const mhmr_lbs_consts* c, const float* rotvec, const float* betas, const float* expr,
+                           const float* loc, const float* dist, const float* K, const int* det_b, int P, float* ws_F,
+                           float* ws_A, float* ws_xf, float* v3d, float* v2d, float* j3d, float* j2d, float* transl,
+                           int* ws_sync, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Anny variant read-outs; the backbone, the detection head and the decoder stack reuse
  * mhmr_vit_forward / mhmr_detect_* / mhmr_xattn_layers_forward.

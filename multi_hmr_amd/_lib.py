@@ -156,6 +156,7 @@ _SIGS = {
     "mhmr_linear_f32": ([_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "mhmr_layernorm_f32": ([_vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
     "mhmr_lbs_forward": ([C.POINTER(LbsConsts)] + [_vp] * 7 + [_i] + [_vp] * 8 + [_vp], _i),
+    "mhmr_lbs_forward_fused": ([C.POINTER(LbsConsts)] + [_vp] * 7 + [_i] + [_vp] * 8 + [_vp, _vp], _i),
     "mhmr_preprocess_u8": ([_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i] + [_i] * 7 + [_vp, _vp, _vp, _vp], _i),
     "mhmr_eval_mesh_errors": ([_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp], _i),
     "mhmr_anny_scores": ([_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),

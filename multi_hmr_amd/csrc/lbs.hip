@@ -27,6 +27,8 @@
 //     vertices behind the real ones (packing.pack_smplx: copies of their corner vertices' operand columns, arranged so that ONE lane ends
 //     up with the three posed corners of an extra joint): they cost 5 of 224 workgroups on otherwise idle CUs instead of a third launch
 //     (round 2: lbs_extra_joints_kernel, 3.4 us + a launch gap behind the vertex kernel).
+#include <stdlib.h>
+#include <stddef.h>
 #include "mhmr_common.h"
 #include "mhmr_internal.h"
 
@@ -64,19 +66,35 @@ __device__ __forceinline__ void project(const float* K, const float* x, float* o
     o2[1] = K[3] * yx + K[4] * yy + K[5] * yz;
 }
 
-__global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, const float* __restrict__ rotvec,
-                                                      const float* __restrict__ betas, const float* __restrict__ expr,
-                                                      const float* __restrict__ loc, const float* __restrict__ dist,
-                                                      const float* __restrict__ Kmat, const int* __restrict__ det_b, int P, int Pp,
-                                                      _Float16* __restrict__ F16, _Float16* __restrict__ A16, float* __restrict__ xf,
-                                                      float* __restrict__ j3d, float* __restrict__ j2d,
-                                                      float* __restrict__ transl_out) {
-    __shared__ float sR[NJ][9], sJ[NJ][3], sRw[NJ][9], sTw[NJ][3], sX[33];
-    __shared__ int sPar[NJ];
+// One person = ONE WAVE: its staging lives in a PoseLds of its own and every synchronisation point is wave-local (LDS accesses of a wave
+// complete in order: a landing wait is all a wave needs to see its own lanes' writes), so the same code runs as a 64-thread workgroup
+// (lbs_pose_kernel) and as one of the twelve waves of a pose-role workgroup of the fused launch (lbs_fused_kernel).
+struct __attribute__((aligned(16))) PoseLds {
+    float sR[NJ][9], sJ[NJ][3], sRw[NJ][9], sTw[NJ][3], sX[36];
+    int sPar[56];
     // the person's two operand rows are collected here and leave as 16-byte chunks (8 consecutive k / joints of one person are 8
     // consecutive f16 of the fragment-major layouts): 2 + 2 x 1.5 wide stores per lane instead of ~50 two-byte ones (round 4)
-    __shared__ __attribute__((aligned(16))) float sF[LBS_KB_POSE], sA[12][64];
-    const int p = blockIdx.x, j = threadIdx.x;
+    __attribute__((aligned(16))) float sF[LBS_KB_POSE];
+    __attribute__((aligned(16))) float sA[12][64];
+};
+static_assert(sizeof(PoseLds) % 16 == 0 && offsetof(PoseLds, sF) % 16 == 0 && offsetof(PoseLds, sA) % 16 == 0, "16-byte chunks");
+#define LBS_WAVE_SYNC()                                        \
+    do {                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+        __builtin_amdgcn_wave_barrier();                       \
+    } while (0)
+
+__device__ __forceinline__ void lbs_pose_person(const mhmr_lbs_consts& c, const float* __restrict__ rotvec,
+                                                const float* __restrict__ betas, const float* __restrict__ expr,
+                                                const float* __restrict__ loc, const float* __restrict__ dist,
+                                                const float* __restrict__ Kmat, const int* __restrict__ det_b, int P, int Pp,
+                                                _Float16* __restrict__ F16, _Float16* __restrict__ A16, float* __restrict__ xf,
+                                                float* __restrict__ j3d, float* __restrict__ j2d,
+                                                float* __restrict__ transl_out, int p, PoseLds& L) {
+    float (&sR)[NJ][9] = L.sR; float (&sJ)[NJ][3] = L.sJ; float (&sRw)[NJ][9] = L.sRw; float (&sTw)[NJ][3] = L.sTw; float (&sX)[36] = L.sX;
+    int (&sPar)[56] = L.sPar;
+    float (&sF)[LBS_KB_POSE] = L.sF; float (&sA)[12][64] = L.sA;
+    const int j = threadIdx.x & 63;
     // Both operands are stored FRAGMENT-MAJOR: the 64 lanes of a wave read one (person group, part, k step) fragment as 1 KiB of
     // consecutive bytes (16 B per lane, lane = 16 * (k group) + person-in-group), i.e. eight whole 128-byte lines per wave
     // instruction; a row-major [person][k] image makes every fragment load touch 16 lines for 64 useful bytes each, and the TA,
@@ -212,7 +230,7 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
         else if (t < ncoef) v = expr[(size_t)p * 10 + (t - c.nb)];
         put_f(k, v);
     }
-    __syncthreads();
+    LBS_WAVE_SYNC();
     // kinematic chain, one tree LEVEL at a time: every joint whose depth equals the level composes its parent's world transform with its
     // own (the 55 joints of SMPL-X sit on 10 levels; a single thread walking the 54 edges took 27 us -- more than the vertex kernel at
     // small person counts)
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) maxdepth = max(maxdepth, __shfl_xor(maxdepth, o));
     for (int level = 1; level <= maxdepth; ++level) {
-        __syncthreads();
+        LBS_WAVE_SYNC();
         if (j < NJ && depth == level) {
             const int pa = sPar[j];
             float Rp[9], Rl[9], Rn[9], rel[3], t[3];
@@ -245,7 +263,7 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
             for (int a = 0; a < 3; ++a) sTw[j][a] = t[a] + sTw[pa][a];
         }
     }
-    __syncthreads();
+    LBS_WAVE_SYNC();
     if (j == 0) {
         // recentring.  person_center joint given: recentre on it (smpl_layer.py:131-136); None (center_joint < 0): the pelvis is ADDED
         // to the translation instead and nothing is recentred (smpl_layer.py:128-130), i.e. o = tr + pelvis
@@ -262,7 +280,7 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
 #pragma unroll
         for (int a = 0; a < 3; ++a) { sX[9 + a] = sTw[0][a]; sX[12 + a] = sX[24 + a] - cc[a]; }
     }
-    __syncthreads();
+    LBS_WAVE_SYNC();
     if (j < 24) xf[(size_t)p * 24 + j] = sX[j];
     if (j >= NJ) {                                     // joints 55..63: zero columns of the skinning operand
         for (int comp = 0; comp < 12; ++comp) put_a(comp, j, 0.f);
@@ -295,8 +313,19 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
         j2d[((size_t)p * 127 + j) * 2] = pr[0];
         j2d[((size_t)p * 127 + j) * 2 + 1] = pr[1];
     }
-    __syncthreads();
+    LBS_WAVE_SYNC();
     flush(false);
+}
+
+__global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, const float* __restrict__ rotvec,
+                                                      const float* __restrict__ betas, const float* __restrict__ expr,
+                                                      const float* __restrict__ loc, const float* __restrict__ dist,
+                                                      const float* __restrict__ Kmat, const int* __restrict__ det_b, int P, int Pp,
+                                                      _Float16* __restrict__ F16, _Float16* __restrict__ A16, float* __restrict__ xf,
+                                                      float* __restrict__ j3d, float* __restrict__ j2d,
+                                                      float* __restrict__ transl_out) {
+    __shared__ PoseLds L;
+    lbs_pose_person(c, rotvec, betas, expr, loc, dist, Kmat, det_b, P, Pp, F16, A16, xf, j3d, j2d, transl_out, (int)blockIdx.x, L);
 }
 
 #ifdef MHMR_LBS_STAMPS      // tools/lbs_timeline.py: per-workgroup s_memtime stamps of wave 0 (debug build only, never in libmhmr.so)
@@ -365,11 +394,14 @@ __device__ __forceinline__ void lbs_barrier() {
 }
 
 // loader wave lw: the tile's basis slice, eighth by eighth, + the person records
+template <bool FUSED>
 __device__ __forceinline__ void lbs_loader(const mhmr_lbs_consts& c, const float* __restrict__ xf, int P, int ngroups, int g0, char* smem,
-                                           int lw) {
+                                           int lw, int tile, int* __restrict__ sync, int ntiles, int Pp) {
     const int lane = threadIdx.x & 63;
     char* xrec = smem + LBS_XOFF;
-    for (int i = lw; i < LBS_NC; i += LBS_NL) {
+    // (fused launch: the records are the pose role's OUTPUT -- every compute wave fetches its own group's after its ready wait, and this
+    // wave's vmcnt stream holds the basis copies only, which is all the landing waits below count)
+    for (int i = FUSED ? LBS_NC : lw; i < LBS_NC; i += LBS_NL) {
         const int g = g0 + i;
         if (g >= ngroups) break;
         const int bytes = min(16, P - 16 * g) * LBS_XREC;
@@ -379,7 +411,7 @@ __device__ __forceinline__ void lbs_loader(const mhmr_lbs_consts& c, const float
             if (k * 1024 + lane * 16 < bytes) glds16(src + k * 1024, xrec + i * (16 * LBS_XREC) + k * 1024);
     }
     // tile-major basis: the tile's slice is one contiguous block, an eighth is 36 consecutive KiB; source and LDS image lane-linear
-    const _Float16* bsrc = (const _Float16*)c.basis16 + (size_t)blockIdx.x * (LBS_TILE_BYTES / 2) + lane * 8;
+    const _Float16* bsrc = (const _Float16*)c.basis16 + (size_t)tile * (LBS_TILE_BYTES / 2) + lane * 8;
     auto dma_e = [&](int e) {          // (e is a compile-time value at every call: the loops around are unrolled)
         char* dst = smem + lbs_eoff(e);
         const int nops = e == LBS_NE - 1 ? LBS_EOPS : LBS_EOPS_HI;
@@ -409,11 +441,25 @@ __device__ __forceinline__ void lbs_loader(const mhmr_lbs_consts& c, const float
         else if (e == 6) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lbs_barrier();                                   // ... and every compute wave is done with eighth e - 1
+        if constexpr (FUSED) {
+            // Barrier 0 lies behind every compute wave's ready wait: this workgroup reads the ready flags no more.  The LAST vertex
+            // workgroup to get here puts the flags and the ticket back to zero -- the workspace leaves the launch as it entered it
+            // (no memset launch, no host-side epoch: the call stays capturable and re-entrant per workspace).
+            if (e == 0 && lw == 0) {
+                int t = 0;
+                if (lane == 0) t = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                t = __builtin_amdgcn_readfirstlane(t);
+                if (t == ntiles - 1) {
+                    for (int i = lane; i < Pp; i += 64) __hip_atomic_store(sync + 1 + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
         if (e + LBS_LEAD < LBS_NE) dma_e(e + LBS_LEAD);
         else if (e == 3) {
             // the tile's dense skin weights (12 KiB, tile-major [8 joint blocks][hi|lo][48][8] = MFMA operand order); the last landing
             // wait (vmcnt(0)) and barrier publish them together with eighth 7
-            const _Float16* wsrc = (const _Float16*)c.skin16 + (size_t)blockIdx.x * (LBS_WBYTES / 2) + lane * 8;
+            const _Float16* wsrc = (const _Float16*)c.skin16 + (size_t)tile * (LBS_WBYTES / 2) + lane * 8;
             char* dst = smem + LBS_WOFF;
 #pragma unroll
             for (int k = 0; k < WOPS; ++k) {
@@ -425,13 +471,37 @@ __device__ __forceinline__ void lbs_loader(const mhmr_lbs_consts& c, const float
 }
 
 // compute wave: person group g (16 persons) against the tile's 48 vertices
+template <bool FUSED>
 __device__ __forceinline__ void lbs_compute(const mhmr_lbs_consts& c, const _Float16* __restrict__ F16, const _Float16* __restrict__ A16,
                                             int P, int ngroups, int g, int w, float* __restrict__ v3d, float* __restrict__ v2d,
-                                            float* __restrict__ j3d, float* __restrict__ j2d, const char* smem) {
+                                            float* __restrict__ j3d, float* __restrict__ j2d, char* smem, int tile,
+                                            const float* __restrict__ xf, const int* __restrict__ sync) {
     typedef Op<MHMR_DT_F16>::V8 H8;
     const int lane = threadIdx.x & 63;
     const int g4 = lane >> 4, l15 = lane & 15;
-    const int v0 = blockIdx.x * LBS_TV;
+    const int v0 = tile * LBS_TV;
+    if constexpr (FUSED) {
+        // the pose role of THIS launch writes F16 / A16 / xf: wait until the sixteen person rows of the group are published (the flag is
+        // stored with release semantics behind the row's data; the acquire fence behind the spin makes the data visible here), then bring the group's
+        // records into this wave's own LDS strip.  The loader waves meanwhile stream the basis: by the time the poses exist, five
+        // eighths of the tile have landed.
+        const int* f = sync + 1 + 16 * g + l15;
+        // (bounded: ~0.5 s of polling means the protocol is broken -- abort the kernel loudly rather than hang the device)
+        int spins = 0;
+        while (!__all(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1 << 22)) __builtin_trap();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // ONE cache invalidation, after the spin
+        float* xr = (float*)(smem + LBS_XOFF + w * (16 * LBS_XREC));
+        const int nfl = min(16, P - 16 * g) * 24;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int k = lane + 64 * i;
+            if (k < nfl) xr[k] = xf[(size_t)g * (16 * 24) + k];
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
 
     // A operands of k step sg (fragment-major: 1 KiB per (group, part, k step)), [set][hi | lo]
     H8 A[2][2];
@@ -604,6 +674,47 @@ __device__ __forceinline__ void lbs_compute(const mhmr_lbs_consts& c, const _Flo
     LBS_STAMP(11);
 }
 
+// ONE launch for the whole layer (round 5): workgroups [0, npose) are the pose role -- twelve persons each, one per wave, exactly
+// lbs_pose_person above -- and workgroups [npose, npose + tiles) the vertex role.  The two used to be two launches: 10.5 us of pose
+// latency chain + a launch gap in front of a vertex kernel whose first 5 us are nothing but the basis stream's ramp.  Here the vertex
+// workgroups start their basis DMA at once and only their compute waves wait for the poses (per-person ready flags in `sync`).
+// Progress: workgroups are dispatched in index order, so the pose workgroups are resident before any waiting one; the launcher also
+// keeps the grid within one workgroup per CU (everything co-resident), and falls back to the two launches otherwise.
+// sync [1 + Pp] ints: [0] a ticket, [1 + p] the ready flag of person row p; ZERO on entry, zero again on exit (lbs_loader).
+__global__ __launch_bounds__(64 * (LBS_NC + LBS_NL), 3) void lbs_fused_kernel(const mhmr_lbs_consts c, const float* __restrict__ rotvec,
+                                                                              const float* __restrict__ betas, const float* __restrict__ expr,
+                                                                              const float* __restrict__ loc, const float* __restrict__ dist,
+                                                                              const float* __restrict__ Kmat, const int* __restrict__ det_b,
+                                                                              int P, int Pp, _Float16* __restrict__ F16,
+                                                                              _Float16* __restrict__ A16, float* __restrict__ xf,
+                                                                              float* __restrict__ v3d, float* __restrict__ v2d,
+                                                                              float* __restrict__ j3d, float* __restrict__ j2d,
+                                                                              float* __restrict__ transl, int* __restrict__ sync, int npose) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if ((int)blockIdx.x < npose) {
+        const int p = (int)blockIdx.x * (LBS_NC + LBS_NL) + w;
+        if (p >= Pp) return;
+        PoseLds& L = *(PoseLds*)(smem + (size_t)w * sizeof(PoseLds));
+        lbs_pose_person(c, rotvec, betas, expr, loc, dist, Kmat, det_b, P, Pp, F16, A16, xf, j3d, j2d, transl, p, L);
+        // publish the row: every lane's stores, then the flag (release, device scope)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_wave_barrier();
+        if ((threadIdx.x & 63) == 0) __hip_atomic_store(sync + 1 + p, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int tile = (int)blockIdx.x - npose, ngroups = Pp / 16, ntiles = (int)gridDim.x - npose;
+    if (w >= LBS_NC) {
+        lbs_loader<true>(c, xf, P, ngroups, 0, smem, w - LBS_NC, tile, sync, ntiles, Pp);
+    } else if (w < ngroups) {
+        lbs_compute<true>(c, F16, A16, P, ngroups, w, w, v3d, v2d, j3d, j2d, smem, tile, xf, sync);
+    } else {
+#pragma unroll
+        for (int e = 0; e < LBS_NE; ++e) lbs_barrier();
+    }
+}
+static_assert((LBS_NC + LBS_NL) * sizeof(PoseLds) <= LBS_LDS, "pose role staging of twelve waves");
+
 __global__ __launch_bounds__(64 * (LBS_NC + LBS_NL), 3) void lbs_vertex_kernel(const mhmr_lbs_consts c, const _Float16* __restrict__ F16,
                                                                                const _Float16* __restrict__ A16, const float* __restrict__ xf,
                                                                                int P, int Pp, int g0, float* __restrict__ v3d,
@@ -615,9 +726,9 @@ __global__ __launch_bounds__(64 * (LBS_NC + LBS_NL), 3) void lbs_vertex_kernel(c
     LBS_STAMP(0);
     // every wave passes the same LBS_NE barriers
     if (w >= LBS_NC) {
-        lbs_loader(c, xf, P, ngroups, g0, smem, w - LBS_NC);
+        lbs_loader<false>(c, xf, P, ngroups, g0, smem, w - LBS_NC, (int)blockIdx.x, nullptr, 0, Pp);
     } else if (g0 + w < ngroups) {
-        lbs_compute(c, F16, A16, P, ngroups, g0 + w, w, v3d, v2d, j3d, j2d, smem);
+        lbs_compute<false>(c, F16, A16, P, ngroups, g0 + w, w, v3d, v2d, j3d, j2d, smem, (int)blockIdx.x, nullptr, nullptr);
     } else {
 #pragma unroll
         for (int e = 0; e < LBS_NE; ++e) lbs_barrier();
@@ -630,10 +741,10 @@ __global__ __launch_bounds__(64 * (LBS_NC + LBS_NL), 3) void lbs_vertex_kernel(c
 extern "C" int mhmr_debug_lbs_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lbs_stamps), &p, sizeof(p)); }
 #endif
 
-extern "C" int mhmr_lbs_forward(const mhmr_lbs_consts* c, const float* rotvec, const float* betas, const float* expr,
-                                const float* loc, const float* dist, const float* Kmat, const int* det_b, int P, float* ws_F,
-                                float* ws_A, float* ws_xf, float* v3d, float* v2d, float* j3d, float* j2d, float* transl,
-                                void* stream) {
+static int lbs_forward_impl(const mhmr_lbs_consts* c, const float* rotvec, const float* betas, const float* expr,
+                            const float* loc, const float* dist, const float* Kmat, const int* det_b, int P, float* ws_F,
+                            float* ws_A, float* ws_xf, float* v3d, float* v2d, float* j3d, float* j2d, float* transl,
+                            int* ws_sync, void* stream) {
     if (!c || P < 0) return MHMR_ERR_BAD_ARG;
     if (P == 0) return 0;
     if (c->Vp % LBS_TV || c->Vl % LBS_TV || c->Vl < c->V || c->Vp != c->Vl + LBS_TV * ((LBS_NX + 15) / 16) || c->Kb != LBS_KB ||
@@ -650,8 +761,22 @@ extern "C" int mhmr_lbs_forward(const mhmr_lbs_consts* c, const float* rotvec, c
         if (need >= 0) {
             hipError_t e = hipFuncSetAttribute((const void*)lbs_vertex_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LBS_LDS);
             if (e != hipSuccess) return (int)e;
+            e = hipFuncSetAttribute((const void*)lbs_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LBS_LDS);
+            if (e != hipSuccess) return (int)e;
             once.mark(dev);
         }
+    }
+    // one launch when the caller gave a (zeroed) sync workspace, one vertex launch covers every person group, and every workgroup of
+    // the fused grid has a CU of its own (MHMR_LBS_FUSED=0: A/B measurements)
+    static const bool fused_env = !(getenv("MHMR_LBS_FUSED") && atoi(getenv("MHMR_LBS_FUSED")) == 0);
+    const int npose = (Pp + LBS_NC + LBS_NL - 1) / (LBS_NC + LBS_NL), ntiles = c->Vp / LBS_TV;
+    if (ws_sync && fused_env && Pp / 16 <= LBS_NC && npose + ntiles <= mhmr_cu_count()) {
+        prof_begin(PROF_LBS, s);
+        hipLaunchKernelGGL(lbs_fused_kernel, dim3(npose + ntiles), dim3(64 * (LBS_NC + LBS_NL)), LBS_LDS, s, *c, rotvec, betas, expr, loc, dist,
+                           Kmat, det_b, P, Pp, (_Float16*)ws_F, (_Float16*)ws_A, ws_xf, v3d, v2d, j3d, j2d, transl, ws_sync, npose);
+        prof_end(PROF_LBS, s, (double)P);
+        MHMR_CHECK_LAUNCH();
+        return 0;
     }
     hipLaunchKernelGGL(lbs_pose_kernel, dim3(Pp), dim3(64), 0, s, *c, rotvec, betas, expr, loc, dist, Kmat, det_b, P, Pp,
                        (_Float16*)ws_F, (_Float16*)ws_A, ws_xf, j3d, j2d, transl);
@@ -665,4 +790,19 @@ extern "C" int mhmr_lbs_forward(const mhmr_lbs_consts* c, const float* rotvec, c
     prof_end(PROF_LBS, s, (double)P);
     MHMR_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int mhmr_lbs_forward(const mhmr_lbs_consts* c, const float* rotvec, const float* betas, const float* expr,
+                                const float* loc, const float* dist, const float* Kmat, const int* det_b, int P, float* ws_F,
+                                float* ws_A, float* ws_xf, float* v3d, float* v2d, float* j3d, float* j2d, float* transl,
+                                void* stream) {
+    return lbs_forward_impl(c, rotvec, betas, expr, loc, dist, Kmat, det_b, P, ws_F, ws_A, ws_xf, v3d, v2d, j3d, j2d, transl, nullptr, stream);
+}
+
+extern "C" int mhmr_lbs_forward_fused(const mhmr_lbs_consts* c, const float* rotvec, const float* betas, const float* expr,
+                                      const float* loc, const float* dist, const float* Kmat, const int* det_b, int P, float* ws_F,
+                                      float* ws_A, float* ws_xf, float* v3d, float* v2d, float* j3d, float* j2d, float* transl,
+                                      int* ws_sync, void* stream) {
+    if (!ws_sync) return MHMR_ERR_BAD_ARG;
+    return lbs_forward_impl(c, rotvec, betas, expr, loc, dist, Kmat, det_b, P, ws_F, ws_A, ws_xf, v3d, v2d, j3d, j2d, transl, ws_sync, stream);
 }

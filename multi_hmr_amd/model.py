@@ -364,6 +364,7 @@ class Model(nn.Module):
         layer = self.smpl_layer[f"neutral_{nb}"]
         P["lbs"] = packing.pack_smplx(self._smplx_data, nb, device, layer.person_center_idx if layer.person_center_idx is not None else -1)
         P["lbs_struct"] = packing.lbs_consts_struct(P["lbs"])
+        P["lbs_sync"] = torch.zeros(1 + 160, dtype=torch.int32, device=device)      # mhmr_lbs_forward_fused: ticket + ready flags
         self._packed = P
         return P
 
@@ -621,8 +622,10 @@ class Model(nn.Module):
         V = lb["V"]
         v3d, v2d, j3d, j2d, transl = o["v3d"], o["v2d"], o["j3d"], o["j2d"], o["transl"]
         ws_F, ws_A, ws_xf = f(roundup(Pn, 16), lb["Kb"]), f(roundup(Pn, 16), 768), f(Pn, 24)
-        _lib.check(L.mhmr_lbs_forward(C.byref(P["lbs_struct"]), rotvec.data_ptr(), shape.data_ptr(), expression.data_ptr(), loc.data_ptr(),
-                                      dist.data_ptr(), K.data_ptr(), det[0].data_ptr(), Pn, ws_F.data_ptr(), ws_A.data_ptr(),
-                                      ws_xf.data_ptr(), v3d.data_ptr(), v2d.data_ptr(), j3d.data_ptr(), j2d.data_ptr(), transl.data_ptr(),
-                                      stream), "mhmr_lbs_forward")
+        # one launch for the layer (pose role + vertex role; up to 160 persons, otherwise the entry falls back to pose + vertex launches);
+        # the flag workspace is the pack's: zeroed once, left zero by every call
+        _lib.check(L.mhmr_lbs_forward_fused(C.byref(P["lbs_struct"]), rotvec.data_ptr(), shape.data_ptr(), expression.data_ptr(), loc.data_ptr(),
+                                            dist.data_ptr(), K.data_ptr(), det[0].data_ptr(), Pn, ws_F.data_ptr(), ws_A.data_ptr(),
+                                            ws_xf.data_ptr(), v3d.data_ptr(), v2d.data_ptr(), j3d.data_ptr(), j2d.data_ptr(), transl.data_ptr(),
+                                            P["lbs_sync"].data_ptr(), stream), "mhmr_lbs_forward_fused")
         return o

@@ -634,6 +634,53 @@ def test_lbs_against_oracle(L, smplx_data, P, center):
     assert float((j3d[:, 76:] - lm).abs().max()) < 2e-6
 
 
+@pytest.mark.parametrize("P", [1, 5, 16, 20, 70, 160, 161, 300])
+def test_lbs_fused_launch_is_bit_identical_and_leaves_its_workspace_clean(L, smplx_data, P):
+    """mhmr_lbs_forward_fused: the pose role as the leading workgroups of the vertex grid, per-person ready flags between them.  Same
+    arithmetic as the two launches of mhmr_lbs_forward -> every output bit-identical; the flag workspace is zero again after every call
+    (the last vertex workgroup clears it), so the SAME workspace serves many calls back to back, with different inputs, without a
+    memset between them; P > 160 takes the two-launch path and never touches the workspace."""
+    import ctypes as C
+    pk = packing.pack_smplx(smplx_data, 10, dev(), 15)
+    cs = packing.lbs_consts_struct(pk)
+    V, B = pk["V"], 4
+    d = lambda t, dt=torch.float32: t.to(device=dev(), dtype=dt).contiguous()
+    f = lambda *s: torch.full(s, float("nan"), device=dev())
+    sync = torch.zeros(1 + packing.roundup(P, 16), dtype=torch.int32, device=dev())
+    if P > 160:
+        sync.fill_(7)                                         # the fallback path must not read or write it
+    K = synthetic.get_camera_K(896, B)
+    K[:, 0, 2] += torch.arange(B) * 4.0
+
+    def inputs(seed):
+        g = torch.Generator(device="cpu").manual_seed(100 * P + seed)
+        pose = 0.35 * torch.randn(P, 53, 3, generator=g)
+        shape, expr = torch.randn(P, 10, generator=g), torch.randn(P, 10, generator=g)
+        det_b = torch.randint(0, B, (P,), generator=g).sort().values
+        loc, dist = 896 * torch.rand(P, 2, generator=g), 2 + 6 * torch.rand(P, 1, generator=g)
+        return [d(pose), d(shape), d(expr), d(loc), d(dist), d(K), d(det_b, torch.int32)]
+
+    def run(fused, args):
+        outs = [f(P, V, 3), f(P, V, 2), f(P, 127, 3), f(P, 127, 2), f(P, 3)]
+        ws = [f(packing.roundup(P, 16), pk["Kb"]), f(packing.roundup(P, 16), 768), f(P, 24)]       # NaN-poisoned: nothing may be read unwritten
+        ptrs = [a.data_ptr() for a in args] + [P] + [w.data_ptr() for w in ws] + [o.data_ptr() for o in outs]
+        if fused:
+            _lib.check(L.mhmr_lbs_forward_fused(C.byref(cs), *ptrs, sync.data_ptr(), stream()), "lbs fused")
+        else:
+            _lib.check(L.mhmr_lbs_forward(C.byref(cs), *ptrs, stream()), "lbs")
+        return outs
+
+    for rep in range(6):                                      # back to back on one stream, new inputs every time, no memset in between
+        args = inputs(rep % 3)
+        got = run(True, args)
+        ref = run(False, args)
+        for name, a, b in zip(("v3d", "v2d", "j3d", "j2d", "transl"), got, ref):
+            assert bool(torch.isfinite(a).all()), (name, rep)
+            assert torch.equal(a, b), (name, rep, float((a - b).abs().max()))
+        torch.cuda.synchronize()
+        assert int(sync.abs().sum()) == (0 if P <= 160 else 7 * sync.numel()), (rep, sync[:8].tolist())
+
+
 def test_lbs_max_abs_gate_160_persons_x_20_seeds(L, smplx_data):
     """The SLP-packed build of the vertex kernel's epilogue once returned, for about one (person, vertex tile) pair in 10^4, a projection
     computed with a zero focal length (csrc/lbs.hip is built with -fno-slp-vectorize, enforced by a compile-time check in the source).
