@@ -425,6 +425,20 @@ __device__ __forceinline__ void lbs_loader(const mhmr_lbs_consts& c, const float
     };
 #pragma unroll
     for (int e = 0; e < LBS_LEAD; ++e) dma_e(e);
+    if constexpr (FUSED) {
+        lbs_barrier();          // the ready barrier: compute wave 0 has seen every person row published (lbs_compute)
+        // This workgroup reads the ready flags no more.  The LAST vertex workgroup to get here puts the flags and the ticket back to
+        // zero -- the workspace leaves the launch as it entered it (no memset launch, no host-side epoch: the call stays capturable).
+        if (lw == 0) {
+            int t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t == ntiles - 1) {
+                for (int i = lane; i < Pp; i += 64) __hip_atomic_store(sync + 1 + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     constexpr int WOPS = LBS_WBYTES / 1024 / LBS_NL;
 #pragma unroll
     for (int e = 0; e < LBS_NE; ++e) {
@@ -441,20 +455,6 @@ __device__ __forceinline__ void lbs_loader(const mhmr_lbs_consts& c, const float
         else if (e == 6) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lbs_barrier();                                   // ... and every compute wave is done with eighth e - 1
-        if constexpr (FUSED) {
-            // Barrier 0 lies behind every compute wave's ready wait: this workgroup reads the ready flags no more.  The LAST vertex
-            // workgroup to get here puts the flags and the ticket back to zero -- the workspace leaves the launch as it entered it
-            // (no memset launch, no host-side epoch: the call stays capturable and re-entrant per workspace).
-            if (e == 0 && lw == 0) {
-                int t = 0;
-                if (lane == 0) t = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                t = __builtin_amdgcn_readfirstlane(t);
-                if (t == ntiles - 1) {
-                    for (int i = lane; i < Pp; i += 64) __hip_atomic_store(sync + 1 + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (lane == 0) __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
         if (e + LBS_LEAD < LBS_NE) dma_e(e + LBS_LEAD);
         else if (e == 3) {
             // the tile's dense skin weights (12 KiB, tile-major [8 joint blocks][hi|lo][48][8] = MFMA operand order); the last landing
@@ -481,18 +481,26 @@ __device__ __forceinline__ void lbs_compute(const mhmr_lbs_consts& c, const _Flo
     const int g4 = lane >> 4, l15 = lane & 15;
     const int v0 = tile * LBS_TV;
     if constexpr (FUSED) {
-        // the pose role of THIS launch writes F16 / A16 / xf: wait until the sixteen person rows of the group are published (the flag is
-        // stored with release semantics behind the row's data; the acquire fence behind the spin makes the data visible here), then bring the group's
-        // records into this wave's own LDS strip.  The loader waves meanwhile stream the basis: by the time the poses exist, five
-        // eighths of the tile have landed.
-        const int* f = sync + 1 + 16 * g + l15;
-        // (bounded: ~0.5 s of polling means the protocol is broken -- abort the kernel loudly rather than hang the device)
-        int spins = 0;
-        while (!__all(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1 << 22)) __builtin_trap();
+        // The pose role of THIS launch writes F16 / A16 / xf.  Compute wave 0 alone polls the ready flags (all person rows of the launch)
+        // and takes the acquire fence -- ONE cache invalidation per workgroup: the per-wave form of the first build cost 2 240 of them and
+        // ran 30 us SLOWER than two launches -- then the workgroup's ready barrier publishes "poses visible" to the other eleven waves.
+        // The loader waves meanwhile stream the basis: by the time the poses exist, five eighths of the tile have landed.
+        if (w == 0) {
+            int spins = 0;      // (bounded: ~0.5 s of polling means the protocol is broken -- abort the kernel loudly rather than hang the device)
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int r = lane + 64 * i;
+                    if (r < 16 * ngroups) ok = ok && __hip_atomic_load(sync + 1 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1;
+                }
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 21)) __builtin_trap();
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // ONE cache invalidation, after the spin
+        lbs_barrier();                                              // the ready barrier (every wave of the workgroup passes it once)
         float* xr = (float*)(smem + LBS_XOFF + w * (16 * LBS_XREC));
         const int nfl = min(16, P - 16 * g) * 24;
 #pragma unroll
@@ -502,7 +510,6 @@ __device__ __forceinline__ void lbs_compute(const mhmr_lbs_consts& c, const _Flo
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
-
     // A operands of k step sg (fragment-major: 1 KiB per (group, part, k step)), [set][hi | lo]
     H8 A[2][2];
     auto load_a = [&](int set, int sg) {          // (the low half only where the pair form of the basis is: the last eighth's two steps)
@@ -694,13 +701,20 @@ __global__ __launch_bounds__(64 * (LBS_NC + LBS_NL), 3) void lbs_fused_kernel(co
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if ((int)blockIdx.x < npose) {
         const int p = (int)blockIdx.x * (LBS_NC + LBS_NL) + w;
-        if (p >= Pp) return;
-        PoseLds& L = *(PoseLds*)(smem + (size_t)w * sizeof(PoseLds));
-        lbs_pose_person(c, rotvec, betas, expr, loc, dist, Kmat, det_b, P, Pp, F16, A16, xf, j3d, j2d, transl, p, L);
-        // publish the row: every lane's stores, then the flag (release, device scope)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __builtin_amdgcn_wave_barrier();
-        if ((threadIdx.x & 63) == 0) __hip_atomic_store(sync + 1 + p, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (p < Pp) {
+            PoseLds& L = *(PoseLds*)(smem + (size_t)w * sizeof(PoseLds));
+            lbs_pose_person(c, rotvec, betas, expr, loc, dist, Kmat, det_b, P, Pp, F16, A16, xf, j3d, j2d, transl, p, L);
+        }
+        // Publish the workgroup's twelve rows with ONE release: every wave's stores have reached the L2 (vmcnt(0)) before the barrier,
+        // wave 0 then writes the L2 back once (a release fence per WAVE is a cache write-back per person: 160 of them serialised per
+        // XCD in the first build) and raises the flags.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lbs_barrier();
+        if (w == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const int lane = threadIdx.x & 63, r = (int)blockIdx.x * (LBS_NC + LBS_NL) + lane;
+            if (lane < LBS_NC + LBS_NL && r < Pp) __hip_atomic_store(sync + 1 + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
     const int tile = (int)blockIdx.x - npose, ngroups = Pp / 16, ntiles = (int)gridDim.x - npose;
@@ -710,7 +724,7 @@ __global__ __launch_bounds__(64 * (LBS_NC + LBS_NL), 3) void lbs_fused_kernel(co
         lbs_compute<true>(c, F16, A16, P, ngroups, w, w, v3d, v2d, j3d, j2d, smem, tile, xf, sync);
     } else {
 #pragma unroll
-        for (int e = 0; e < LBS_NE; ++e) lbs_barrier();
+        for (int e = 0; e < LBS_NE + 1; ++e) lbs_barrier();         // the ready barrier + the eight of the blend
     }
 }
 static_assert((LBS_NC + LBS_NL) * sizeof(PoseLds) <= LBS_LDS, "pose role staging of twelve waves");
