@@ -339,7 +339,9 @@ int mhmr_lbs_forward(const mhmr_lbs_consts* c, const float* rotvec, const float*
                      float* ws_A, float* ws_xf, float* v3d, float* v2d, float* j3d, float* j2d, float* transl,
                      void* stream);
 
-/* The same layer as ONE launch (round 5): the pose work (Rodrigues, joint regression, kinematic chain: a 10 us latency chain) runs as the
+/* The same layer as ONE launch (round 5) -- built, tested bit-identical, and measured SLOWER than the two launches on MI355X (48.7 vs 40.2 us
+ * at 160 persons: cross-XCD visibility costs an L2 write-back + invalidation, csrc/lbs.hip), so multi_hmr_amd.Model calls
+ * mhmr_lbs_forward unless the environment says MHMR_LBS_FUSED=1.  The fused form: the pose work (Rodrigues, joint regression, kinematic chain: a 10 us latency chain) runs as the
  * leading workgroups of the vertex grid while the other workgroups already stream the blend basis; per-person ready flags in ws_sync
  * order the two.  ws_sync: [1 + roundup(P,16)] ints, ZERO before the first call; every call leaves it zero again (so a workspace can be
  * allocated and cleared once and reused by every later call on the same stream; two calls in flight need two workspaces).  Results are

@@ -681,7 +681,7 @@ __device__ __forceinline__ void lbs_compute(const mhmr_lbs_consts& c, const _Flo
     LBS_STAMP(11);
 }
 
-// ONE launch for the whole layer (round 5): workgroups [0, npose) are the pose role -- twelve persons each, one per wave, exactly
+// ONE launch for the whole layer (round 5; opt-in, see lbs_forward_impl for the measurement that keeps it off): workgroups [0, npose) are the pose role -- twelve persons each, one per wave, exactly
 // lbs_pose_person above -- and workgroups [npose, npose + tiles) the vertex role.  The two used to be two launches: 10.5 us of pose
 // latency chain + a launch gap in front of a vertex kernel whose first 5 us are nothing but the basis stream's ramp.  Here the vertex
 // workgroups start their basis DMA at once and only their compute waves wait for the poses (per-person ready flags in `sync`).
@@ -780,11 +780,15 @@ static int lbs_forward_impl(const mhmr_lbs_consts* c, const float* rotvec, const
             once.mark(dev);
         }
     }
-    // one launch when the caller gave a (zeroed) sync workspace, one vertex launch covers every person group, and every workgroup of
-    // the fused grid has a CU of its own (MHMR_LBS_FUSED=0: A/B measurements)
-    static const bool fused_env = !(getenv("MHMR_LBS_FUSED") && atoi(getenv("MHMR_LBS_FUSED")) == 0);
+    // The fused launch is CORRECT (bit-identical outputs, tests/test_gpu_kernels.py) and SLOWER than the two launches on this chip
+    // (profiles/r05_session_c_lbs_fused_slp.txt: 48.7 vs 40.2 us at 160 persons, 38.3 vs 30.2 at 20, 32.2 vs 26.6 at 1), so it runs only
+    // through its own entry point (mhmr_lbs_forward_fused; Model takes it with MHMR_LBS_FUSED=1).  Why it loses: (a) across XCDs the poses become visible only through an L2 write-back on the
+    // producer side and an L2 invalidation on the consumer side (one each per workgroup in this form; one per WAVE in the first form: 76 us);
+    // (b) the vertex role's time at small person counts is not the basis stream's ramp, as assumed, but its SEQUENCING -- only five of
+    // the eight eighths fit in flight before the poses exist (LDS, vmcnt budget), the other three and the skin weights are latency-bound
+    // rounds that need the compute waves' barriers, i.e. the poses: what overlaps is ~5 us, what the fences cost is about the same.
     const int npose = (Pp + LBS_NC + LBS_NL - 1) / (LBS_NC + LBS_NL), ntiles = c->Vp / LBS_TV;
-    if (ws_sync && fused_env && Pp / 16 <= LBS_NC && npose + ntiles <= mhmr_cu_count()) {
+    if (ws_sync && Pp / 16 <= LBS_NC && npose + ntiles <= mhmr_cu_count()) {
         prof_begin(PROF_LBS, s);
         hipLaunchKernelGGL(lbs_fused_kernel, dim3(npose + ntiles), dim3(64 * (LBS_NC + LBS_NL)), LBS_LDS, s, *c, rotvec, betas, expr, loc, dist,
                            Kmat, det_b, P, Pp, (_Float16*)ws_F, (_Float16*)ws_A, ws_xf, v3d, v2d, j3d, j2d, transl, ws_sync, npose);

@@ -622,10 +622,13 @@ class Model(nn.Module):
         V = lb["V"]
         v3d, v2d, j3d, j2d, transl = o["v3d"], o["v2d"], o["j3d"], o["j2d"], o["transl"]
         ws_F, ws_A, ws_xf = f(roundup(Pn, 16), lb["Kb"]), f(roundup(Pn, 16), 768), f(Pn, 24)
-        # one launch for the layer (pose role + vertex role; up to 160 persons, otherwise the entry falls back to pose + vertex launches);
-        # the flag workspace is the pack's: zeroed once, left zero by every call
-        _lib.check(L.mhmr_lbs_forward_fused(C.byref(P["lbs_struct"]), rotvec.data_ptr(), shape.data_ptr(), expression.data_ptr(), loc.data_ptr(),
-                                            dist.data_ptr(), K.data_ptr(), det[0].data_ptr(), Pn, ws_F.data_ptr(), ws_A.data_ptr(),
-                                            ws_xf.data_ptr(), v3d.data_ptr(), v2d.data_ptr(), j3d.data_ptr(), j2d.data_ptr(), transl.data_ptr(),
-                                            P["lbs_sync"].data_ptr(), stream), "mhmr_lbs_forward_fused")
+        # pose kernel + vertex kernel; MHMR_LBS_FUSED=1: the one-launch form (pose role = leading workgroups of the vertex grid), built and
+        # bit-identical but measured slower on this chip (csrc/lbs.hip) -- its flag workspace is the pack's: zeroed once, left zero by every call
+        args = [C.byref(P["lbs_struct"]), rotvec.data_ptr(), shape.data_ptr(), expression.data_ptr(), loc.data_ptr(), dist.data_ptr(), K.data_ptr(),
+                det[0].data_ptr(), Pn, ws_F.data_ptr(), ws_A.data_ptr(), ws_xf.data_ptr(), v3d.data_ptr(), v2d.data_ptr(), j3d.data_ptr(), j2d.data_ptr(),
+                transl.data_ptr()]
+        if os.environ.get("MHMR_LBS_FUSED") == "1":
+            _lib.check(L.mhmr_lbs_forward_fused(*args, P["lbs_sync"].data_ptr(), stream), "mhmr_lbs_forward_fused")
+        else:
+            _lib.check(L.mhmr_lbs_forward(*args, stream), "mhmr_lbs_forward")
         return o

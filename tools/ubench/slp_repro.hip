@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
+#include <math.h>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void mfma_kernel(const f16x8* __restrict__ src
 // epilogue); bad[0] counts lane-iterations whose LOW half differs, bad[1] HIGH half, bad[2 + lane] per-lane low-half failures.
 template <int NOPS>
 __global__ __launch_bounds__(256) void pk_kernel(const f32x2* __restrict__ xs, const f32x2* __restrict__ ms, const f32x2* __restrict__ cs,
-                                                 int n, int iters, unsigned* __restrict__ bad) {
+                                                 int n, int iters, unsigned* __restrict__ bad, float* __restrict__ ex) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     unsigned lo_bad = 0, hi_bad = 0;
     for (int it = 0; it < iters; ++it) {
@@ -63,8 +64,18 @@ __global__ __launch_bounds__(256) void pk_kernel(const f32x2* __restrict__ xs, c
         float r0, r1;
         asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r0) : "v"(x[0]), "v"(m[1]), "v"(c[0]));
         asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r1) : "v"(x[1]), "v"(m[1]), "v"(c[1]));
-        lo_bad += __builtin_bit_cast(uint32_t, d[0]) != __builtin_bit_cast(uint32_t, r0);
-        hi_bad += __builtin_bit_cast(uint32_t, d[1]) != __builtin_bit_cast(uint32_t, r1);
+        const bool lb = __builtin_bit_cast(uint32_t, d[0]) != __builtin_bit_cast(uint32_t, r0);
+        const bool hb = __builtin_bit_cast(uint32_t, d[1]) != __builtin_bit_cast(uint32_t, r1);
+        lo_bad += lb;
+        hi_bad += hb;
+        if (lb || hb) {       // the first few offending tuples of each kind: [kind, lane, x0, x1, m0, m1, c0, c1, d0, d1, r0, r1]
+            const unsigned slot = atomicAdd(bad + 66 + (lb ? 0 : 1), 1u);
+            if (slot < 8) {
+                float* e = ex + ((lb ? 0 : 8) + slot) * 12;
+                e[0] = lb ? 0.f : 1.f; e[1] = (float)lane; e[2] = x[0]; e[3] = x[1]; e[4] = m[0]; e[5] = m[1]; e[6] = c[0]; e[7] = c[1];
+                e[8] = d[0]; e[9] = d[1]; e[10] = r0; e[11] = r1;
+            }
+        }
     }
     if (lo_bad) { atomicAdd(bad, lo_bad); atomicAdd(bad + 2 + lane, lo_bad); }
     if (hi_bad) atomicAdd(bad + 1, hi_bad);
@@ -81,7 +92,9 @@ int main(int argc, char** argv) {
     float* sink;
     unsigned* bad;
     CK(hipMalloc(&xs, n * sizeof(f32x2))); CK(hipMalloc(&ms, n * sizeof(f32x2))); CK(hipMalloc(&cs, n * sizeof(f32x2)));
-    CK(hipMalloc(&src, 128 * sizeof(f16x8))); CK(hipMalloc(&sink, 4)); CK(hipMalloc(&bad, 66 * 4));
+    CK(hipMalloc(&src, 128 * sizeof(f16x8))); CK(hipMalloc(&sink, 4)); CK(hipMalloc(&bad, 68 * 4));
+    float* ex;
+    CK(hipMalloc(&ex, 16 * 12 * 4));
     {
         float* h = (float*)malloc(3 * n * 2 * sizeof(float));
         srand(7);
@@ -96,10 +109,12 @@ int main(int argc, char** argv) {
     }
     hipStream_t sp, sm;
     CK(hipStreamCreate(&sp)); CK(hipStreamCreate(&sm));
-    unsigned hb[66];
+    unsigned hb[68];
+    float hex_[16 * 12];
     for (int nops = 0; nops < 2; ++nops) {
         for (int mode = 0; mode < 2; ++mode) {       // 0: pk kernel alone (control), 1: under the MFMA kernel on a second stream
-            CK(hipMemset(bad, 0, 66 * 4));
+            CK(hipMemset(bad, 0, 68 * 4));
+            CK(hipMemset(ex, 0, sizeof(hex_)));
             CK(hipDeviceSynchronize());
             hipEvent_t e0, e1;
             CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -107,8 +122,8 @@ int main(int argc, char** argv) {
             for (int l = 0; l < launches; ++l) {
                 // one MFMA workgroup per CU (4 waves: one per SIMD), ~2 ms each, re-launched so that it is ALWAYS there while P runs
                 if (mode == 1 && (l % 4) == 0) hipLaunchKernelGGL(mfma_kernel, dim3(prop.multiProcessorCount), dim3(256), 0, sm, src, sink, 6000);
-                if (nops == 0) hipLaunchKernelGGL((pk_kernel<0>), dim3(grid), dim3(256), 0, sp, xs, ms, cs, n, iters, bad);
-                else hipLaunchKernelGGL((pk_kernel<1>), dim3(grid), dim3(256), 0, sp, xs, ms, cs, n, iters, bad);
+                if (nops == 0) hipLaunchKernelGGL((pk_kernel<0>), dim3(grid), dim3(256), 0, sp, xs, ms, cs, n, iters, bad, ex);
+                else hipLaunchKernelGGL((pk_kernel<1>), dim3(grid), dim3(256), 0, sp, xs, ms, cs, n, iters, bad, ex);
             }
             CK(hipEventRecord(e1, sp));
             CK(hipDeviceSynchronize());
@@ -119,6 +134,15 @@ int main(int argc, char** argv) {
             printf("%s, %s: %d launches, %.3g packed FMAs, %.1f ms: low-half mismatches %u, high-half mismatches %u\n",
                    nops ? "s_nop 4 in front" : "bare instruction", mode ? "UNDER the MFMA kernel (second stream)" : "alone (control)", launches, total,
                    msec, hb[0], hb[1]);
+            CK(hipMemcpy(hex_, ex, sizeof(hex_), hipMemcpyDeviceToHost));
+            for (int k = 0; k < 16; ++k) {
+                const float* e = hex_ + k * 12;
+                if (e[2] == 0.f && e[3] == 0.f) continue;
+                if (k >= 8 && k >= 10) continue;         // two high-half examples are enough
+                printf("  %s-half example, lane %2d: x = (%.9g, %.9g) m = (%.9g, %.9g) c = (%.9g, %.9g) -> packed (%.9g, %.9g), scalar fma(x0, m1, c0) = %.9g, fma(x1, m1, c1) = %.9g;"
+                       " fma(x0, m0, c0) = %.9g, fma(x1, m0, c1) = %.9g\n", e[0] == 0.f ? "LOW" : "HIGH", (int)e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8], e[9], e[10], e[11],
+                       fmaf(e[2], e[4], e[6]), fmaf(e[3], e[4], e[7]));
+            }
             if (hb[0]) {
                 printf("  per-lane low-half failures:");
                 for (int i = 0; i < 64; ++i) if (hb[2 + i]) printf(" %d:%u", i, hb[2 + i]);
