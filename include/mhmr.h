@@ -74,6 +74,13 @@ typedef struct {
     int flags;
     const float* qkv_colsum;      /* [3C] or NULL */
     const float* fc1_colsum;      /* [4C] or NULL */
+    /* The same low halves for the fp8 low-half range of the big GEMMs (mhmr_vit_desc.lo8; round 5): rows of 3C BYTES = [W_hi: C op16 values |
+     * e4m3(W_lo * 2^-e): C bytes], *_w8_scale = 127 + e (the E8M0 scale byte).  The weight's low half corrects the high half's 2^-12
+     * rounding: it needs three significant bits, not eleven, and the fp8 matrix pipe runs at twice the 16-bit rate.  NULL = that linear
+     * keeps the op16 low half (v_w2 / proj_w2, which the class-row kernel uses in either case).  For a folded V the rows hold W diag(w_ln). */
+    const void* v_w8;
+    const void* proj_w8;
+    int v_w8_scale, proj_w8_scale;
 } mhmr_vit_block;
 
 typedef struct {
@@ -113,6 +120,10 @@ typedef struct {
      *   fc1_w [4C, 3C], fc2_w [C, 12C]); v_w2 / proj_w2 NULL, flags 0;  Tp % 128 == 0 (Tp % 256 for C % 256 == 0: every linear on the
      *   256x256 kernel); a_patch op16 [roundup(B*N,128), 2 Kp], xn / att op16 [B*Tp, 2C], hid op16 [B*Tp, 8C] = [hi | lo];
      *   qk, vt, attn_flags, pstats, rowstats unused (may be NULL). */
+    /* lo8 != 0: `xn` and `att` are op16 [B*Tp, 3C/2] -- every row = [C op16 values | C bytes: the bf8 (e5m2) copy of the same values],
+     * written by their producers (LayerNorm kernel, residual epilogue, attention) where the next linear has an fp8 low-half range
+     * (blocks[i].v_w8 / proj_w8); C % 256 == 0.  lo8 == 0: rows of C op16 values, v_w8 / proj_w8 ignored. */
+    int lo8;
     int x3;
     float* qkv32;           /* x3: [B*Tp, 3C] fp32  (Q | K | V), bias included                                                 */
     float* hid32;           /* x3: [B*Tp, 4C] fp32  fc1 output before the GELU                                                 */
@@ -143,6 +154,14 @@ int mhmr_gemm16_ln(const void* A, int lda, const void* W, int ldw, int M, int N,
                    int a_k, void* x16, float* pstats, const float* rowstats, const float* colsum, const float* fbias, void* stream);
 /* rowstats[b*Tp + n] = (mean, rstd) of residual row (b, n): n < N from the block sums pstats[b*Tp + n][C/64][2], n == N (the class row)
  * from the fp32 row resid[b*Tp + N][C] itself.                                                                                       */
+/* mhmr_gemm16_ln with an fp8 low-half range (csrc/gemm256.hip, GemmArgs::lo8; epi = MHMR_EPI_VT or MHMR_EPI_RESID only): A rows = [a_k op16 |
+ * a_k bytes bf8 (e5m2) of the same values] (lda >= 3 a_k / 2), W rows = [a_k op16 | a_k bytes e4m3 of W_lo * 2^-e], w8_scale = 127 + e;
+ * K is implied (a_k + a_k / 2 in 16-bit units), a_k % 256 == 0.  Producer side (MHMR_EPI_RESID, x16 != NULL): ldx16 = row pitch of x16 in
+ * elements (0 = ldo) and x8_off > 0 = byte offset inside an x16 row for the bf8 copy of the new residual values.  lo8 = 0 makes it
+ * mhmr_gemm16_ln with the producer's pitch options (then K = a_k, one pass). */
+int mhmr_gemm16_lo8(const void* A, int lda, const void* W, int ldw, int M, int N, int a_k, int lo8, int w8_scale, const float* bias,
+                    const float* gamma, void* out, int ldo, int Tp, int H, int epi, int dtype, int img_rows, int img_stride, void* x16,
+                    int ldx16, int x8_off, float* pstats, const float* rowstats, const float* colsum, const float* fbias, void* stream);
 int mhmr_ln_stats(const float* pstats, const float* resid, float* rowstats, int B, int N, int Tp, int C, float eps, void* stream);
 /* The class-token rows of a block linear (csrc/vit_cls.hip): B rows, a_stride / o_stride elements apart.  epi 0: Q | K | V projection
  * (columns n_base + [0, N) of [Q * MHMR_ATTN_QSCALE | K | V]; Q, K -> out16 row, V -> column vcol of vt [B,H,64,Tp]); epi 1: out32 +=
@@ -175,6 +194,13 @@ int mhmr_attention16(const void* qk, const void* vt, void* out, int B, int T, in
 int mhmr_attention16_ex(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype,
                         float limit_log2, int variant, int* flags, void* stream);
 int mhmr_attention_flag_count(int B, int Tp, int H);
+/* variant 6 of mhmr_attention16_ex into rows of pitch ldo elements (>= C), with the bf8 (e5m2) copy of every output row at byte offset
+ * o8 of the row (0 = none; 2C <= o8, o8 + C <= 2 ldo): the A operand of an output projection with an fp8 low-half range. */
+int mhmr_attention16_pitch(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, int* flags, int ldo,
+                           int o8, void* stream);
+/* mhmr_layernorm16 into rows of pitch ld16 elements, with the bf8 copy at byte offset o8 (0 = none). */
+int mhmr_layernorm16_pitch(const float* in, const float* w, const float* b, void* out16, int ld16, int o8, int rows, int C, float eps,
+                           int dtype, void* stream);
 /* The attention of the f16x3 mode (csrc/attention_f32.hip): qkv fp32 [B*Tp, 3C] = (Q | K | V) un-scaled, head h at columns h*64;
  * out op16 PAIR [B*Tp, 2C] = [hi | lo] of softmax(Q K^T / 8) V over the T real keys; every product on v_mfma_f32_16x16x4_f32 (exact fp32).
  * Rows >= T of an image are written as zeros or as the (finite) attention of a padding row: never left unwritten.   Tp % 64 == 0. */

@@ -98,7 +98,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 class VitBlock(C.Structure):
     _fields_ = ([(n, _vp) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1", "ln2_w", "ln2_b",
                                     "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "v_w2", "proj_w2")] +
-                [("flags", _i), ("qkv_colsum", _vp), ("fc1_colsum", _vp)])
+                [("flags", _i), ("qkv_colsum", _vp), ("fc1_colsum", _vp), ("v_w8", _vp), ("proj_w8", _vp), ("v_w8_scale", _i), ("proj_w8_scale", _i)])
 
 
 class VitDesc(C.Structure):
@@ -106,7 +106,7 @@ class VitDesc(C.Structure):
                 [("patch_w", _vp), ("patch_b", _vp), ("cls_pos0", _vp), ("pos", _vp), ("blocks", C.POINTER(VitBlock)),
                  ("norm_w", _vp), ("norm_b", _vp)] +
                 [(n, _vp) for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid", "attn_flags", "pstats", "rowstats")] +
-                [("x3", _i), ("qkv32", _vp), ("hid32", _vp)])
+                [("lo8", _i), ("x3", _i), ("qkv32", _vp), ("hid32", _vp)])
 
 
 class HphLayer(C.Structure):
@@ -135,11 +135,14 @@ _SIGS = {
     "mhmr_gemm16": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mhmr_gemm16_ex": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mhmr_gemm16_ln": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "mhmr_gemm16_lo8": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
     "mhmr_ln_stats": ([_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
     "mhmr_cls_linear16": ([_vp, C.c_longlong, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, C.c_longlong, _i, _i, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "mhmr_attention16": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mhmr_attention16_ex": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp], _i),
     "mhmr_attention_flag_count": ([_i, _i, _i], _i),
+    "mhmr_attention16_pitch": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp], _i),
+    "mhmr_layernorm16_pitch": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp], _i),
     "mhmr_attention_f32": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mhmr_layernorm16_pair": ([_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp], _i),
     "mhmr_gelu16_pair": ([_vp, _vp, C.c_longlong, _i, _i, _vp], _i),

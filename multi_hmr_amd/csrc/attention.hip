@@ -74,7 +74,8 @@ constexpr float BAND = 8.f;                 // MODE 2: half-width of the band ar
 template <int DT, int NW, int RING, int MODE>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
     const void* __restrict__ qk_, const void* __restrict__ vt_, void* __restrict__ out_, int T, int Tp, int C, int H, int nqt,
-    float limit, int* __restrict__ flags) {
+    float limit, int* __restrict__ flags, int ldo, int o8) {
+    // ldo: row pitch of `out` in elements (C, or wider when a row also carries its bf8 copy); o8 > 0: byte offset of that copy inside a row
     typedef typename Op<DT>::T Tt;
     typedef typename Op<DT>::V8 V8;
     typedef typename Op<DT>::V4 V4;
@@ -351,15 +352,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
     if (!in_buf) return;
     int lane3 = lane;
     asm volatile("" : "+v"(lane3));                               // (the store address is formed here, not carried through the loop)
-    Tt* op = (Tt*)out_ + (row0 + (qt * QB + 32 * w + (lane3 & 31))) * C + h * 64 + 4 * (lane3 >> 5);
+    Tt* op = (Tt*)out_ + (row0 + (qt * QB + 32 * w + (lane3 & 31))) * (size_t)ldo + h * 64 + 4 * (lane3 >> 5);
+    char* op8 = (char*)((Tt*)out_ + (row0 + (qt * QB + 32 * w + (lane3 & 31))) * (size_t)ldo) + o8 + h * 64 + 4 * (lane3 >> 5);
 #pragma unroll
     for (int ds = 0; ds < 2; ++ds)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             V4 v;
+            float f[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (Tt)(o[ds][4 * rg + e] * inv);
+            for (int e = 0; e < 4; ++e) { f[e] = o[ds][4 * rg + e] * inv; v[e] = (Tt)f[e]; }
             *(V4*)(op + 32 * ds + 8 * rg) = v;
+            if (o8 > 0) *(uint32_t*)(op8 + 32 * ds + 8 * rg) = pack_bf8x4(f[0], f[1], f[2], f[3]);      // the output projection's fp8 low-half range
         }
 }
 
@@ -678,7 +682,8 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(const void* __restrict__
 //   lone last key's dot product close over them with two lane exchanges each.
 template <int DT>
 __global__ __launch_bounds__(256, 4) void attn16_kernel(const void* __restrict__ qk_, const void* __restrict__ vt_, void* __restrict__ out_,
-                                                        int T, int Tp, int C, int H, int nqt, float limit, int* __restrict__ flags) {
+                                                        int T, int Tp, int C, int H, int nqt, float limit, int* __restrict__ flags, int ldo,
+                                                        int o8) {
     typedef typename Op<DT>::T Tt;
     typedef typename Op<DT>::V8 V8;
     typedef typename Op<DT>::V4 V4;
@@ -906,26 +911,29 @@ __global__ __launch_bounds__(256, 4) void attn16_kernel(const void* __restrict__
         l_tot += __shfl_xor(l_tot, 16);
         l_tot += __shfl_xor(l_tot, 32);
         const float inv = active ? 1.0f / l_tot : 0.f;
-        Tt* op = (Tt*)out_ + (row0 + (qt * QB + 32 * w + 16 * qb + (lane3 & 15))) * C + h * 64 + 4 * (lane3 >> 4);
+        Tt* op = (Tt*)out_ + (row0 + (qt * QB + 32 * w + 16 * qb + (lane3 & 15))) * (size_t)ldo + h * 64 + 4 * (lane3 >> 4);
+        char* op8 = (char*)((Tt*)out_ + (row0 + (qt * QB + 32 * w + 16 * qb + (lane3 & 15))) * (size_t)ldo) + o8 + h * 64 + 4 * (lane3 >> 4);
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
             V4 v;
+            float f[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (Tt)(o[db][qb][e] * inv);
+            for (int e = 0; e < 4; ++e) { f[e] = o[db][qb][e] * inv; v[e] = (Tt)f[e]; }
             *(V4*)(op + 16 * db) = v;
+            if (o8 > 0) *(uint32_t*)(op8 + 16 * db) = pack_bf8x4(f[0], f[1], f[2], f[3]);      // the output projection's fp8 low-half range
         }
     }
 }
 
 int launch_attn16(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit, int* flags,
-                  hipStream_t s) {
+                  hipStream_t s, int ldo, int o8) {
     const int nqt = (Tp + 127) / 128;
     const int grid = nqt * H * B;
     const size_t lds = 2 * 2 * KV_TILE_BYTES + 4 * 256;
     if (dtype == MHMR_DT_F16)
-        hipLaunchKernelGGL((attn16_kernel<MHMR_DT_F16>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags);
+        hipLaunchKernelGGL((attn16_kernel<MHMR_DT_F16>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags, ldo, o8);
     else
-        hipLaunchKernelGGL((attn16_kernel<MHMR_DT_BF16>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags);
+        hipLaunchKernelGGL((attn16_kernel<MHMR_DT_BF16>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags, ldo, o8);
     MHMR_CHECK_LAUNCH();
     return 0;
 }
@@ -946,15 +954,16 @@ int launch_attn64(const void* qk, const void* vt, void* out, int B, int T, int T
 
 template <int NW, int RING, int MODE>
 int launch_attn(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit, int* flags,
-                hipStream_t s) {
+                hipStream_t s, int ldo = 0, int o8 = 0) {
+    if (ldo <= 0) ldo = C;
     constexpr int QB = 32 * NW;
     const int nqt = (Tp + QB - 1) / QB;
     const int grid = nqt * H * B;
     const size_t lds = RING * 2 * KV_TILE_BYTES + NW * 256;        // K / V^T ring + one 64-float strip per wave (MODE 3's last key)
     if (dtype == MHMR_DT_F16)
-        hipLaunchKernelGGL((attn_kernel<MHMR_DT_F16, NW, RING, MODE>), dim3(grid), dim3(64 * NW), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags);
+        hipLaunchKernelGGL((attn_kernel<MHMR_DT_F16, NW, RING, MODE>), dim3(grid), dim3(64 * NW), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags, ldo, o8);
     else
-        hipLaunchKernelGGL((attn_kernel<MHMR_DT_BF16, NW, RING, MODE>), dim3(grid), dim3(64 * NW), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags);
+        hipLaunchKernelGGL((attn_kernel<MHMR_DT_BF16, NW, RING, MODE>), dim3(grid), dim3(64 * NW), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags, ldo, o8);
     MHMR_CHECK_LAUNCH();
     return 0;
 }
@@ -974,8 +983,17 @@ int mhmr_attention_flag_count_impl(int B, int Tp, int H) { return 4 * ((Tp + 127
 // fragments and the V^T fragments requested ahead of their MFMAs (sched_barrier-pinned; 3 waves per SIMD, or 4 with spills)
 // 840-918: LDS latency is not what bounds the kernel, the VALU work per tile and the 128-register budget are (a form that kept
 // the exact rescale inside the loop next to the sum test needed all 128 registers and fell to one LDS read per MFMA: 850).
+int mhmr_launch_attention_pitch(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit_log2,
+                                int variant, int* flags, hipStream_t s, int ldo, int o8);
 int mhmr_launch_attention_ex(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit_log2,
                              int variant, int* flags, hipStream_t s) {
+    return mhmr_launch_attention_pitch(qk, vt, out, B, T, Tp, C, H, dtype, limit_log2, variant, flags, s, C, 0);
+}
+// ldo: row pitch of `out` in elements (>= C); o8 > 0: byte offset inside an out row where the bf8 (e5m2) copy of the row's C values goes
+// (GemmArgs::lo8 of the output projection).  Only the default form (variant 6 + its fallback) takes a pitch other than C.
+int mhmr_launch_attention_pitch(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit_log2,
+                                int variant, int* flags, hipStream_t s, int ldo, int o8) {
+    if ((ldo != C || o8 != 0) && (variant != 6 || ldo < C || o8 < 0 || (o8 > 0 && (o8 < 2 * C || o8 + C > 2 * ldo)))) return MHMR_ERR_BAD_ARG;
     if (C != H * 64 || Tp % 64 || T > Tp || T <= 0 || limit_log2 < 0.f || limit_log2 > 15.f) return MHMR_ERR_BAD_SHAPE;
     if ((variant == 0 || variant == 6) && flags == nullptr) return MHMR_ERR_BAD_ARG;
     const float limit = exp2f(limit_log2);
@@ -1000,8 +1018,8 @@ int mhmr_launch_attention_ex(const void* qk, const void* vt, void* out, int B, i
         }
         case 6: {     // MODE 3 arithmetic on v_mfma_f32_16x16x32 (attn16_kernel) + the gated textbook fallback
             if (flags == nullptr) return MHMR_ERR_BAD_ARG;
-            rc = launch_attn16(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
-            if (!rc) rc = launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
+            rc = launch_attn16(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8);
+            if (!rc) rc = launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8);
             break;
         }
         default: return MHMR_ERR_BAD_ARG;
@@ -1011,8 +1029,8 @@ int mhmr_launch_attention_ex(const void* qk, const void* vt, void* out, int B, i
 }
 
 int mhmr_launch_attention(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, int* flags,
-                          hipStream_t s) {
+                          hipStream_t s, int ldo = 0, int o8 = 0) {
     static const char* v = getenv("MHMR_ATTN_VARIANT");      // A/B measurements only
     const int variant = v ? atoi(v) : (flags ? MHMR_ATTN_DEFAULT_VARIANT : 2);
-    return mhmr_launch_attention_ex(qk, vt, out, B, T, Tp, C, H, dtype, 15.f, variant, flags, s);
+    return mhmr_launch_attention_pitch(qk, vt, out, B, T, Tp, C, H, dtype, 15.f, variant, flags, s, ldo > 0 ? ldo : C, o8);
 }

@@ -7,7 +7,9 @@
 #include "mhmr_internal.h"
 
 // launchers defined in the other translation units
-int mhmr_launch_attention(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, int* flags, hipStream_t s);
+int mhmr_launch_attention(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, int* flags, hipStream_t s, int ldo = 0, int o8 = 0);
+int mhmr_launch_layernorm_pitch(const float* in, const float* w, const float* b, void* out16, int ld16, int o8, int rows, int C, float eps, int dtype, hipStream_t s);
+bool mhmr_gemm256_eligible(const GemmArgs& g);
 int mhmr_launch_attention_ex(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit_log2, int variant, int* flags, hipStream_t s);
 int mhmr_attention_flag_count_impl(int B, int Tp, int H);
 int mhmr_launch_im2col(const float* x, void* a, int B, int S, int G, int Kp, int dtype, hipStream_t s);
@@ -146,6 +148,37 @@ int mhmr_gemm16_ln(const void* A, int lda, const void* W, int ldw, int M, int N,
     return mhmr_launch_gemm(g, dtype, (hipStream_t)stream);
 }
 
+int mhmr_gemm16_lo8(const void* A, int lda, const void* W, int ldw, int M, int N, int a_k, int lo8, int w8_scale, const float* bias,
+                    const float* gamma, void* out, int ldo, int Tp, int H, int epi, int dtype, int img_rows, int img_stride, void* x16,
+                    int ldx16, int x8_off, float* pstats, const float* rowstats, const float* colsum, const float* fbias, void* stream) {
+    const int K = lo8 ? a_k + a_k / 2 : a_k;
+    GemmArgs g{A, lda, W, ldw, M, N, K, bias, gamma, out, ldo, nullptr, 0, Tp, H, M, epi};
+    g.img_rows = img_rows;
+    g.img_stride = img_stride;
+    g.a_k = lo8 ? a_k : 0;
+    g.lo8 = lo8;
+    g.w8_scale = w8_scale;
+    g.x16 = x16;
+    g.ldx16 = ldx16;
+    g.x8_off = x8_off;
+    g.pstats = pstats;
+    g.rowstats = rowstats;
+    g.colsum = colsum;
+    g.fbias = fbias;
+    return mhmr_launch_gemm(g, dtype, (hipStream_t)stream);
+}
+
+int mhmr_attention16_pitch(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, int* flags, int ldo,
+                           int o8, void* stream) {
+    if (!flags) return MHMR_ERR_BAD_ARG;
+    return mhmr_launch_attention(qk, vt, out, B, T, Tp, C, H, dtype, flags, (hipStream_t)stream, ldo, o8);
+}
+
+int mhmr_layernorm16_pitch(const float* in, const float* w, const float* b, void* out16, int ld16, int o8, int rows, int C, float eps,
+                           int dtype, void* stream) {
+    return mhmr_launch_layernorm_pitch(in, w, b, out16, ld16, o8, rows, C, eps, dtype, (hipStream_t)stream);
+}
+
 int mhmr_ln_stats(const float* pstats, const float* resid, float* rowstats, int B, int N, int Tp, int C, float eps, void* stream) {
     return mhmr_launch_ln_stats(pstats, resid, rowstats, B, N, Tp, C, eps, (hipStream_t)stream);
 }
@@ -274,6 +307,16 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
                                           : mhmr_launch_ln_stats(d->pstats, d->resid, d->rowstats, 1, M, M, C, 1e-6f, s); };
     const long long rowC = (long long)Tp * C;
     const float* cls_stats = fold ? d->rowstats + (size_t)cls_row * 2 : nullptr;      // (mean, rstd) of image b's class row: + b * 2 Tp
+    // fp8 low-half ranges (mhmr_vit_desc.lo8): the rows of `xn` and `att` are 3C/2 elements wide (the bf8 copy of a row behind its C values)
+    static const bool lo8_env = !(getenv("MHMR_LO8") && atoi(getenv("MHMR_LO8")) == 0);
+    const bool lo8 = d->lo8 != 0 && C % 256 == 0;
+    if (d->lo8 && !lo8) return MHMR_ERR_BAD_SHAPE;
+    const int pit = lo8 ? C + C / 2 : C;                        // row pitch of xn / att in elements
+    const long long rowP = (long long)Tp * pit;
+    const int o8 = 2 * C;                                       // byte offset of the bf8 copy inside such a row
+    // does this block's V / output projection run its low half as an fp8 range?  (needs the 256x256 kernel for that launch; MHMR_LO8=0: A/B)
+    auto v8 = [&](const mhmr_vit_block& k) { return lo8 && lo8_env && k.v_w8 && (rowmap || allrows256); };
+    auto p8 = [&](const mhmr_vit_block& k) { return lo8 && lo8_env && k.proj_w8 && (rowmap || allrows256); };
     for (int l = 0; l < d->L; ++l) {
         const mhmr_vit_block& k = d->blocks[l];
         if (!fold && k.flags) return MHMR_ERR_BAD_ARG;               // folded weights cannot run through the plain LayerNorm path
@@ -282,18 +325,26 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
         if (l == 0 && (k.flags & 1)) return MHMR_ERR_BAD_ARG;
         if (((k.flags & 1) && !k.qkv_colsum) || ((k.flags & 2) && !k.fc1_colsum)) return MHMR_ERR_BAD_ARG;
         const bool f1 = fold && (k.flags & 1), f2 = fold && (k.flags & 2);
-        // the V and output projections may carry the low halves of their weights ([W_hi | W_lo] along k, one accumulator chain)
-        const void* v_w = k.v_w2 ? k.v_w2 : (const void*)((const char*)k.qkv_w + (size_t)2 * C * C * esz);
-        const int v_k = k.v_w2 ? 2 * C : C, v_ak = k.v_w2 ? C : 0;
-        const void* p_w = k.proj_w2 ? k.proj_w2 : k.proj_w;
-        const int p_k = k.proj_w2 ? 2 * C : C, p_ak = k.proj_w2 ? C : 0;
+        // the V and output projections may carry the low halves of their weights ([W_hi | W_lo] along k, one accumulator chain): as an
+        // fp8 range of 128-deep k tiles (v_w8 / proj_w8) or as a second 16-bit range (v_w2 / proj_w2)
+        const bool vlo8 = v8(k), plo8 = p8(k);
+        const void* v_w = vlo8 ? k.v_w8 : k.v_w2 ? k.v_w2 : (const void*)((const char*)k.qkv_w + (size_t)2 * C * C * esz);
+        const int v_k = vlo8 ? pit : k.v_w2 ? 2 * C : C, v_ak = (vlo8 || k.v_w2) ? C : 0;
+        const void* p_w = plo8 ? k.proj_w8 : k.proj_w2 ? k.proj_w2 : k.proj_w;
+        const int p_k = plo8 ? pit : k.proj_w2 ? 2 * C : C, p_ak = (plo8 || k.proj_w2) ? C : 0;
+        // the class-row kernel keeps the 16-bit low halves
+        const void* v_wc = k.v_w2 ? k.v_w2 : (const void*)((const char*)k.qkv_w + (size_t)2 * C * C * esz);
+        const int v_kc = k.v_w2 ? 2 * C : C, v_akc = k.v_w2 ? C : 0;
+        const void* p_wc = k.proj_w2 ? k.proj_w2 : k.proj_w;
+        const int p_kc = k.proj_w2 ? 2 * C : C, p_akc = k.proj_w2 ? C : 0;
         // x = x + ls1 * proj(MHSA(norm1(x)))
         if (f1) TRY(ln_stats());
-        else TRY(mhmr_launch_layernorm(d->resid, k.ln1_w, k.ln1_b, d->xn, M, C, 1e-6f, dt, s));
+        else TRY(mhmr_launch_layernorm_pitch(d->resid, k.ln1_w, k.ln1_b, d->xn, pit, vlo8 ? o8 : 0, M, C, 1e-6f, dt, s));
         {
-            GemmArgs g{d->xn, C, k.qkv_w, C, Mg, 2 * C, C, k.qkv_b, nullptr, d->qk, 2 * C, nullptr, 0, Tp, d->H, Mg, EPI_OP16_QK};
-            GemmArgs gv{d->xn, C, v_w, v_k, Mg, C, v_k, k.qkv_b + 2 * C, nullptr, d->vt, 0, nullptr, 0, Tp, d->H, Mg, EPI_VT};
+            GemmArgs g{d->xn, pit, k.qkv_w, C, Mg, 2 * C, C, k.qkv_b, nullptr, d->qk, 2 * C, nullptr, 0, Tp, d->H, Mg, EPI_OP16_QK};
+            GemmArgs gv{d->xn, pit, v_w, v_k, Mg, C, v_k, k.qkv_b + 2 * C, nullptr, d->vt, 0, nullptr, 0, Tp, d->H, Mg, EPI_VT};
             gv.a_k = v_ak;
+            if (vlo8) { gv.lo8 = 1; gv.w8_scale = k.v_w8_scale; }
             rows(g); rows(gv);
             if (f1) {
                 g.bias = nullptr; g.rowstats = d->rowstats; g.colsum = k.qkv_colsum; g.fbias = k.qkv_b;
@@ -302,51 +353,56 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
             TRY(mhmr_launch_gemm(g, dt, s));
             TRY(mhmr_launch_gemm(gv, dt, s));
             if (rowmap) {
-                const char* xr = (const char*)d->xn + (size_t)cls_row * C * esz;
+                const char* xr = (const char*)d->xn + (size_t)cls_row * pit * esz;
                 char* qr = (char*)d->qk + (size_t)cls_row * 2 * C * esz;
                 const float* st = f1 ? cls_stats : nullptr;
                 // (Q | K and V separately when V carries a low half: different k extents)
                 const int nqk = k.v_w2 ? 2 * C : 3 * C;
-                TRY(mhmr_launch_cls_linear_fold(xr, rowC, k.qkv_w, C, B, nqk, C, 0, f1 ? nullptr : k.qkv_b, nullptr, qr, 2 * rowC, 0, C, d->vt, d->H,
+                TRY(mhmr_launch_cls_linear_fold(xr, rowP, k.qkv_w, C, B, nqk, C, 0, f1 ? nullptr : k.qkv_b, nullptr, qr, 2 * rowC, 0, C, d->vt, d->H,
                                                 Tp, vcol, 0, dt, st, 2LL * Tp, k.qkv_colsum, k.qkv_b, nullptr, 0, s));
                 if (k.v_w2)
-                    TRY(mhmr_launch_cls_linear_fold(xr, rowC, v_w, v_k, B, C, v_k, v_ak, f1 ? nullptr : k.qkv_b + 2 * C, nullptr, qr, 2 * rowC, 2 * C, C,
+                    TRY(mhmr_launch_cls_linear_fold(xr, rowP, v_wc, v_kc, B, C, v_kc, v_akc, f1 ? nullptr : k.qkv_b + 2 * C, nullptr, qr, 2 * rowC, 2 * C, C,
                                                     d->vt, d->H, Tp, vcol, 0, dt, st, 2LL * Tp, f1 ? k.qkv_colsum + 2 * C : nullptr,
                                                     k.qkv_b + 2 * C, nullptr, 0, s));
             }
         }
-        TRY(mhmr_launch_attention(d->qk, d->vt, d->att, B, d->T, Tp, C, d->H, dt, d->attn_flags, s));
+        TRY(mhmr_launch_attention(d->qk, d->vt, d->att, B, d->T, Tp, C, d->H, dt, d->attn_flags, s, pit, plo8 ? o8 : 0));
         {
-            GemmArgs g{d->att, C, p_w, p_k, Mg, C, p_k, k.proj_b, k.ls1, d->resid, C, nullptr, 0, Tp, d->H, Mg, EPI_RESID};
+            GemmArgs g{d->att, pit, p_w, p_k, Mg, C, p_k, k.proj_b, k.ls1, d->resid, C, nullptr, 0, Tp, d->H, Mg, EPI_RESID};
             g.a_k = p_ak;
+            if (plo8) { g.lo8 = 1; g.w8_scale = k.proj_w8_scale; }
             rows(g);
-            if (fold) { g.x16 = d->xn; g.pstats = d->pstats; }
+            if (fold) { g.x16 = d->xn; g.pstats = d->pstats; g.ldx16 = lo8 ? pit : 0; }
             TRY(mhmr_launch_gemm(g, dt, s));
             if (rowmap)
-                TRY(mhmr_launch_cls_linear_fold((const char*)d->att + (size_t)cls_row * C * esz, rowC, p_w, p_k, B, C, p_k, p_ak, k.proj_b, k.ls1,
+                TRY(mhmr_launch_cls_linear_fold((const char*)d->att + (size_t)cls_row * pit * esz, rowP, p_wc, p_kc, B, C, p_kc, p_akc, k.proj_b, k.ls1,
                                                 d->resid + (size_t)cls_row * C, rowC, 0, C, nullptr, d->H, Tp, 0, 1, dt, nullptr, 0, nullptr, nullptr,
-                                                fold ? (char*)d->xn + (size_t)cls_row * C * esz : nullptr, rowC, s));
+                                                fold ? (char*)d->xn + (size_t)cls_row * pit * esz : nullptr, rowP, s));
         }
         // x = x + ls2 * fc2(gelu(fc1(norm2(x))))
         if (f2) TRY(ln_stats());
-        else TRY(mhmr_launch_layernorm(d->resid, k.ln2_w, k.ln2_b, d->xn, M, C, 1e-6f, dt, s));
+        else TRY(mhmr_launch_layernorm_pitch(d->resid, k.ln2_w, k.ln2_b, d->xn, pit, 0, M, C, 1e-6f, dt, s));
         {
-            GemmArgs g{d->xn, C, k.fc1_w, C, Mg, 4 * C, C, k.fc1_b, nullptr, d->hid, 4 * C, nullptr, 0, Tp, d->H, Mg, EPI_OP16_GELU};
+            GemmArgs g{d->xn, pit, k.fc1_w, C, Mg, 4 * C, C, k.fc1_b, nullptr, d->hid, 4 * C, nullptr, 0, Tp, d->H, Mg, EPI_OP16_GELU};
             rows(g);
             if (f2) { g.bias = nullptr; g.rowstats = d->rowstats; g.colsum = k.fc1_colsum; g.fbias = k.fc1_b; }
             TRY(mhmr_launch_gemm(g, dt, s));
             if (rowmap)
-                TRY(mhmr_launch_cls_linear_fold((const char*)d->xn + (size_t)cls_row * C * esz, rowC, k.fc1_w, C, B, 4 * C, C, 0, f2 ? nullptr : k.fc1_b,
+                TRY(mhmr_launch_cls_linear_fold((const char*)d->xn + (size_t)cls_row * pit * esz, rowP, k.fc1_w, C, B, 4 * C, C, 0, f2 ? nullptr : k.fc1_b,
                                                 nullptr, (char*)d->hid + (size_t)cls_row * 4 * C * esz, 4 * rowC, 0, C, nullptr, d->H, Tp, 0, 2, dt,
                                                 f2 ? cls_stats : nullptr, 2LL * Tp, k.fc1_colsum, k.fc1_b, nullptr, 0, s));
             GemmArgs g2{d->hid, 4 * C, k.fc2_w, 4 * C, Mg, C, 4 * C, k.fc2_b, k.ls2, d->resid, C, nullptr, 0, Tp, d->H, Mg, EPI_RESID};
             rows(g2);
-            if (fold) { g2.x16 = d->xn; g2.pstats = d->pstats; }
+            if (fold) {
+                // the rows this epilogue leaves are the NEXT block's qkv operand: with their bf8 copy if that block's V has an fp8 range
+                g2.x16 = d->xn; g2.pstats = d->pstats; g2.ldx16 = lo8 ? pit : 0;
+                g2.x8_off = (l + 1 < d->L && v8(d->blocks[l + 1])) ? o8 : 0;
+            }
             TRY(mhmr_launch_gemm(g2, dt, s));
             if (rowmap)
                 TRY(mhmr_launch_cls_linear_fold((const char*)d->hid + (size_t)cls_row * 4 * C * esz, 4 * rowC, k.fc2_w, 4 * C, B, C, 4 * C, 0, k.fc2_b,
                                                 k.ls2, d->resid + (size_t)cls_row * C, rowC, 0, C, nullptr, d->H, Tp, 0, 1, dt, nullptr, 0, nullptr,
-                                                nullptr, fold ? (char*)d->xn + (size_t)cls_row * C * esz : nullptr, rowC, s));
+                                                nullptr, fold ? (char*)d->xn + (size_t)cls_row * pit * esz : nullptr, rowP, s));
         }
     }
     return mhmr_launch_final_norm(d->resid, d->norm_w, d->norm_b, ctx16, ldctx, feat32, B, d->N, Tp, C, 1e-6f, dt, s);

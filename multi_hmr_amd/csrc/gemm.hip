@@ -288,8 +288,10 @@ int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s) {
     if (g.epi == EPI_VT && (g.Tp % 64 || g.N % 64)) return MHMR_ERR_BAD_SHAPE;
     if (g.epi == EPI_VT && (g.img_rows > 0 ? g.img_rows : g.Tp) % BM && (g_force_gemm128 || !mhmr_gemm256_eligible(g))) return MHMR_ERR_BAD_SHAPE;   // (this kernel's row tile)
     if (g.img_rows > 0 && (g.img_rows % BM || g.M % g.img_rows || g.img_stride < g.img_rows || g.epi == EPI_PATCH)) return MHMR_ERR_BAD_SHAPE;
-    if (g.a_k > 0 && (g.a_k % BK || (g.K != 2 * g.a_k && g.K != 3 * g.a_k) || g.ldw < g.K || (g.K == 3 * g.a_k && g.lda < 2 * g.a_k))) return MHMR_ERR_BAD_SHAPE;
+    if (g.a_k > 0 && !g.lo8 && (g.a_k % BK || (g.K != 2 * g.a_k && g.K != 3 * g.a_k) || g.ldw < g.K || (g.K == 3 * g.a_k && g.lda < 2 * g.a_k))) return MHMR_ERR_BAD_SHAPE;
     if (g.epi == EPI_OP16_QK && g.N % 128) return MHMR_ERR_BAD_SHAPE;      // Q | K halves are whole 64-column blocks
+    if (g.lo8 && (g_force_gemm128 || !mhmr_gemm256_eligible(g))) return MHMR_ERR_BAD_SHAPE;      // fp8 low-half range: 256x256 kernel only
+    if ((g.x8_off > 0 || g.ldx16 > 0) && !g.x16) return MHMR_ERR_BAD_ARG;
     if (g.x16 || g.pstats || g.rowstats) {       // LayerNorm fold: 256x256 kernel only
         if (g_force_gemm128 || !mhmr_gemm256_eligible(g)) return MHMR_ERR_BAD_SHAPE;
         if (g.rowstats && g.K < 256) return MHMR_ERR_BAD_SHAPE;      // (the strip DMA of a tile needs a barrier-separated k pair in front of it)
@@ -319,6 +321,6 @@ int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s) {
         rc = mhmr_launch_gemm256(g2, dtype, s);
     }
     else rc = dtype == MHMR_DT_F16 ? launch_dt<MHMR_DT_F16>(g, s) : launch_dt<MHMR_DT_BF16>(g, s);
-    prof_end(PROF_GEMM, s, 2.0 * g.M * g.N * g.K);
+    prof_end(PROF_GEMM, s, 2.0 * g.M * g.N * (g.lo8 ? 2.0 * g.a_k : (double)g.K));      // (an fp8 range covers a_k more k in a_k / 2 units)
     return rc;
 }

@@ -28,6 +28,7 @@
 //   Persistent: a block walks its output tiles; the K-tile indices t2, t3 that run past the end of one tile are the
 //   first K tiles of the NEXT tile, so the ring stays full across tile boundaries and the next tile's operands stream
 //   in underneath the epilogue (which transposes through its own LDS region and finishes with one vmcnt(0)).
+#include <type_traits>
 #include "mhmr_common.h"
 #include "mhmr_internal.h"
 
@@ -39,6 +40,50 @@ constexpr int SLOT_P0 = 0, SLOT_P1 = HT, SLOT_Q0 = 2 * HT, SLOT_Q1 = 3 * HT;
 constexpr int STAGE_OFF = 2 * BUF;  // 8 waves x 4 KiB epilogue staging (the LayerNorm-foldable epilogues: 8 x 2 KiB + the 4 KiB strip)
 constexpr int STRIP_OFF = STAGE_OFF + 8 * 2048;
 constexpr int LDS_BYTES = 2 * BUF + 8 * 4096;
+
+// An operand fragment of one 16-row sub-tile and one 64-k tile: two 16-byte halves (k steps 0 / 1 of the 16-bit MFMA).  The LO8 form keeps
+// them as ONE 256-bit value -- the eight consecutive registers v_mfma_scale_f32_16x16x128_f8f6f4 takes as an operand.
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+template <typename V8, bool L8> struct Frag;
+template <typename V8> struct Frag<V8, false> {
+    V8 k[2];
+    __device__ __forceinline__ void set(int ks, V8 x) { k[ks] = x; }
+    __device__ __forceinline__ V8 get(int ks) const { return k[ks]; }
+    // (never executed: the fp8 form exists in LO8 kernels only; keeps the generic k-pair lambda well-formed for both fragment types)
+    __device__ __forceinline__ v8i_t raw() const {
+        return __builtin_shufflevector(__builtin_bit_cast(v4i_t, k[0]), __builtin_bit_cast(v4i_t, k[1]), 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+};
+template <typename V8> struct Frag<V8, true> {
+    v8i_t v;
+    __device__ __forceinline__ void set(int ks, V8 x) {
+        const v4i_t t = __builtin_bit_cast(v4i_t, x);
+        if (ks == 0) v = __builtin_shufflevector(t, __builtin_shufflevector(v, v, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7);
+        else v = __builtin_shufflevector(__builtin_shufflevector(v, v, 0, 1, 2, 3), t, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    __device__ __forceinline__ V8 get(int ks) const {
+        return __builtin_bit_cast(V8, ks == 0 ? __builtin_shufflevector(v, v, 0, 1, 2, 3) : __builtin_shufflevector(v, v, 4, 5, 6, 7));
+    }
+    __device__ __forceinline__ v8i_t raw() const { return v; }
+};
+
+// acc += A(16 x 128 fp8) . B(128 x 16 fp8), IN PLACE.  Inline assembly on purpose: this LLVM has no tied-accumulator ("mac") form of the
+// builtin __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4 -- every call writes a FRESH destination quad, which doubles the live
+// accumulators of the k loop (500-670 B of scratch per lane, reloaded between the MFMAs); "+v" ties destination and addend.  AFMT / BFMT: 0 =
+// e4m3, 1 = e5m2 (cbsz / blgp); sa / sb: E8M0 scale bytes of the lane's 32-k block (byte 0 of the register).  Hazards: the eight
+// accumulators of a phase are distinct and next touched a barrier later; the operands come from LDS reads (the compiler's waitcnt pass
+// covers inline-asm uses) and the scale registers are loop invariants.  (Also tried: ONE k loop with a per-phase branch between this and the
+// 16-bit builtin -- the accumulators became phi values and neither arm updated them in place; both arms as inline assembly -- 130-220 B of
+// scratch; hence two k loops, the 16-bit one on the builtin.)
+template <int AFMT, int BFMT>
+__device__ __forceinline__ void mfma_fp8_inplace(f32x4& c, v8i_t a, v8i_t b, int sa, int sb) {
+    static_assert((AFMT == 0 && BFMT == 1) || (AFMT == 1 && BFMT == 0), "weight e4m3 x activation e5m2");
+    if constexpr (AFMT == 0)
+        asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] blgp:1" : "+v"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+    else
+        asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:1" : "+v"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+}
 
 // sum over the 16 lanes of a DPP row, on the VALU (quad xor 1, quad xor 2, half-row mirror, row mirror); every lane ends with the sum
 template <int CTRL>
@@ -66,7 +111,10 @@ __device__ int g_gemm_sametile;      // 1: every tile reads the operands of tile
 
 // FOLD: a consumer of a folded LayerNorm (GemmArgs::rowstats; EPI_OP16_QK / EPI_VT / EPI_OP16_GELU only) -- a kernel of its own, so that
 // the plain epilogues keep their 32-row staging passes and carry no run-time switches
-template <int DT, int EPI, bool FOLD = false>
+// LO8 (GemmArgs::lo8): the k tiles behind a_k are fp8 tiles of 128 k.  A lane's two 16-byte fragments of a row (k steps 0 and 1 of a 16-bit
+// tile) are exactly the 32 bytes v_mfma_scale_f32_16x16x128_f8f6f4 wants from it (which 32 of the row's 128 k a lane holds is a permutation
+// of k applied to both operands alike), so the ring, the copies and the fragment reads are those of the 16-bit tiles: only the MFMA differs.
+template <int DT, int EPI, bool FOLD = false, bool LO8 = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
@@ -102,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
     const int nt = g.K / 64;
     const int nta = g.a_k > 0 ? g.a_k / 64 : nt;                     // k tiles of the activation operand (low-half weight pass: nt = 2 nta)
-    auto ka = [&](int t) { return t >= nta ? t - nta : t; };
+    auto ka = [&](int t) { return (!LO8 && t >= nta) ? t - nta : t; };       // (LO8: the activation row carries its own fp8 range, no wrap-around)
     // an operand position = a wave-uniform 64-bit TILE base (scalar registers; any M x K) + a 32-bit element offset inside the tile
     // (< 256 rows: fits for every ld below 2^22): half the vector registers of per-lane 64-bit pointers
     const uint32_t p_lane = (uint32_t)srow * (uint32_t)ldp + (uint32_t)(schunk * 8);
@@ -127,7 +175,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         pb = Pm + (size_t)(ROWMAJOR ? p0 : ar) * (size_t)ldp;
         qb = Qm + (size_t)(ROWMAJOR ? ar : q0) * (size_t)ldq;
     };
+    // LO8 kernels: the lane-derived address terms (DMA lane offset, fragment offsets) are RE-MADE where they are used, from an mbcnt the
+    // optimiser cannot hoist (a dozen VALU operations per phase, nothing beside 16 MFMAs): kept live across the k loops they were eleven
+    // registers too many for the residual-epilogue variant -- spilled, and every reload's vmcnt(0) drained the DMA ring.
+    auto fresh_lane = [&]() {
+        int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(ln));
+        return ln;
+    };
     auto dma = [&](const T* base, uint32_t lane_off, int ld, int half, int kt, int lds_off) {
+        if constexpr (LO8) {
+            const int t2 = w * 64 + fresh_lane();
+            lane_off = (uint32_t)(t2 >> 3) * (uint32_t)ld + (uint32_t)((((t2 & 7) ^ ((t2 >> 4) & 7))) * 8);
+        }
         const uint32_t o = lane_off + (uint32_t)(128 * half) * (uint32_t)ld + (uint32_t)(kt * 64);
         char* d = smem + lds_off + w * 1024;
         glds16(base + o, d);
@@ -142,28 +202,63 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     for (int ks = 0; ks < 2; ++ks) co[ks] = ((4 * ks + g4) ^ fsw) * 16;
 
     f32x4 acc[2][2][4][2];   // [P half][Q half][16-row P sub-tile][16-row Q sub-tile]
-    V8 PR[4][2], QA[2][2], QB[2][2];
+    typedef Frag<V8, LO8> Fr;
+    Fr PR[4], QA[2], QB[2];
 
     auto rdP = [&](int buf, int slot) {
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) PR[ps][ks] = *(const V8*)(smem + buf * BUF + slot + pr_off + ps * 2048 + co[ks]);
-    };
-    auto rdQ = [&](V8 (&Q)[2][2], int buf, int slot) {
-#pragma unroll
-        for (int qs = 0; qs < 2; ++qs)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) Q[qs][ks] = *(const V8*)(smem + buf * BUF + slot + q_off + qs * 2048 + co[ks]);
-    };
-    auto mma = [&](f32x4 (&c)[4][2], const V8 (&Q)[2][2]) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        if constexpr (LO8) {
+            const int ln = fresh_lane(), a15 = ln & 15, sw = a15 >> 1, gg = ln >> 4;
+            const int po = (64 * wp + a15) * 128, c0 = (gg ^ sw) * 16, c1 = ((4 + gg) ^ sw) * 16;
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps)
 #pragma unroll
-                for (int qs = 0; qs < 2; ++qs) c[ps][qs] = Op<DT>::mfma16(PR[ps][ks], Q[qs][ks], c[ps][qs]);
+                for (int ks = 0; ks < 2; ++ks) PR[ps].set(ks, *(const V8*)(smem + buf * BUF + slot + po + ps * 2048 + (ks ? c1 : c0)));
+        } else {
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) PR[ps].set(ks, *(const V8*)(smem + buf * BUF + slot + pr_off + ps * 2048 + co[ks]));
+        }
+    };
+    auto rdQ = [&](Fr (&Q)[2], int buf, int slot) {
+        if constexpr (LO8) {
+            const int ln = fresh_lane(), a15 = ln & 15, sw = a15 >> 1, gg = ln >> 4;
+            const int qo = (32 * wq + a15) * 128, c0 = (gg ^ sw) * 16, c1 = ((4 + gg) ^ sw) * 16;
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) Q[qs].set(ks, *(const V8*)(smem + buf * BUF + slot + qo + qs * 2048 + (ks ? c1 : c0)));
+        } else {
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) Q[qs].set(ks, *(const V8*)(smem + buf * BUF + slot + q_off + qs * 2048 + co[ks]));
+        }
+    };
+    // E8M0 scales of the fp8 tiles, loop invariants pinned in registers (not re-made by a v_mov in front of an MFMA)
+    [[maybe_unused]] int w8s = g.w8_scale * 0x01010101, a8s = 0x7F7F7F7F;
+    if constexpr (LO8) asm volatile("" : "+v"(w8s), "+v"(a8s));
+    // LOWC: std::true_type for a pair of fp8 k tiles -- a compile-time choice: the k loop exists twice (16-bit tiles, then fp8 tiles), so
+    // that no run-time branch makes the accumulators phi values
+    auto mma = [&](f32x4 (&c)[4][2], const Fr (&Q)[2], auto lowc) {
+        constexpr bool LOW = decltype(lowc)::value;
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (LOW) {
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) {
+                    if constexpr (ROWMAJOR) mfma_fp8_inplace<0, 1>(c[ps][qs], PR[ps].raw(), Q[qs].raw(), w8s, a8s);
+                    else mfma_fp8_inplace<1, 0>(c[ps][qs], PR[ps].raw(), Q[qs].raw(), a8s, w8s);
+                }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+                    for (int qs = 0; qs < 2; ++qs) c[ps][qs] = Op<DT>::mfma16(PR[ps].get(ks), Q[qs].get(ks), c[ps][qs]);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
 #define MHMR_SYNC()                          \
@@ -231,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         const bool has_next = r + 1 < nmine;
         if (has_next) tile_src(tile_of(r + 1), p_nxt, q_nxt, p0n, q0n, arn, bimgn);
         else { p_nxt = p_src; q_nxt = q_src; p0n = p0; q0n = q0; arn = ar; bimgn = bimg; }     // last tile: harmless re-load into slots nobody reads
-        for (int t = 0; t < nt; t += 2) {
+        auto kpair = [&](int t, auto lowc) {
             // K-tile indices past the end of this tile are the first K tiles of the next one
             const bool wrap = t + 2 >= nt;
             const T* p2 = wrap ? p_nxt : p_src;
@@ -257,37 +352,41 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
             // phase 1
             rdP(0, SLOT_P0);
             dma(p_src, p_lane, ldp, 1, t1p, BUF + SLOT_P1); MHMR_WAIT_DMA();
-            MHMR_SYNC(); mma(acc[0][0], QA); MHMR_SYNC();
+            MHMR_SYNC(); mma(acc[0][0], QA, lowc); MHMR_SYNC();
             // phase 2
             rdQ(QB, 0, SLOT_Q1);
             dma(q2, q_lane, ldq, 0, t2q, SLOT_Q0); MHMR_WAIT_DMA();
-            MHMR_SYNC(); mma(acc[0][1], QB); MHMR_SYNC();
+            MHMR_SYNC(); mma(acc[0][1], QB, lowc); MHMR_SYNC();
             // phase 3
             rdP(0, SLOT_P1);
             dma(p2, p_lane, ldp, 0, t2p, SLOT_P0); MHMR_WAIT_DMA();
-            MHMR_SYNC(); mma(acc[1][1], QB); MHMR_SYNC();
+            MHMR_SYNC(); mma(acc[1][1], QB, lowc); MHMR_SYNC();
             // phase 4
             rdQ(QB, 1, SLOT_Q1);
             dma(q2, q_lane, ldq, 1, t2q, SLOT_Q1); MHMR_WAIT_DMA();
-            MHMR_SYNC(); mma(acc[1][0], QA); MHMR_SYNC();
+            MHMR_SYNC(); mma(acc[1][0], QA, lowc); MHMR_SYNC();
             // phase 5
             rdP(1, SLOT_P0);
             dma(p2, p_lane, ldp, 1, t2p, SLOT_P1); MHMR_WAIT_DMA();
-            MHMR_SYNC(); mma(acc[0][1], QB); MHMR_SYNC();
+            MHMR_SYNC(); mma(acc[0][1], QB, lowc); MHMR_SYNC();
             // phase 6
             rdQ(QA, 1, SLOT_Q0);
             dma(q2, q_lane, ldq, 1, t3q, BUF + SLOT_Q1); MHMR_WAIT_DMA();
-            MHMR_SYNC(); mma(acc[0][0], QA); MHMR_SYNC();
+            MHMR_SYNC(); mma(acc[0][0], QA, lowc); MHMR_SYNC();
             // phase 7
             rdP(1, SLOT_P1);
             dma(p2, p_lane, ldp, 0, t3p, BUF + SLOT_P0); MHMR_WAIT_DMA();
-            MHMR_SYNC(); mma(acc[1][0], QA); MHMR_SYNC();
+            MHMR_SYNC(); mma(acc[1][0], QA, lowc); MHMR_SYNC();
             // phase 8 (the next pair's Q0; at the end of a tile it is read after the epilogue instead, so that QA's registers are
             // free for the epilogue)
             if (!wrap) rdQ(QA, 0, SLOT_Q0);
             dma(q2, q_lane, ldq, 0, t3q, BUF + SLOT_Q0); MHMR_WAIT_DMA();
-            MHMR_SYNC(); mma(acc[1][1], QB); MHMR_SYNC();
-        }
+            MHMR_SYNC(); mma(acc[1][1], QB, lowc); MHMR_SYNC();
+        };
+        // the 16-bit k tiles, then (LO8) the fp8 k tiles behind a_k: whole pairs either way (a_k % 256 == 0)
+        for (int t = 0; t < (LO8 ? nta : nt); t += 2) kpair(t, std::false_type{});
+        if constexpr (LO8)
+            for (int t = nta; t < nt; t += 2) kpair(t, std::true_type{});
 
         GEMM_STAMP(r, 1);
         if (wp == 0) { MHMR_SYNC(); }       // re-align: both groups run the memory-bound epilogue together
@@ -360,7 +459,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                         V4 o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = (T)nv[e];
-                        *(V4*)((char*)g.x16 + (off >> 1)) = o;
+                        // x16 rows may be wider than the output's (GemmArgs::ldx16: a row also carries its bf8 copy at byte x8_off): the
+                        // same walk as rptr's with the x16 pitch -- no division (with ldx16 = ldo this is off >> 1)
+                        if (g.ldx16 > 0) {
+                            const uint32_t prow = (uint32_t)(ar + 32 * wq + (lane >> 4)) + (uint32_t)(4 * (32 * j + 4 * qs + it));
+                            const uint32_t pcol = (uint32_t)(p0 + 64 * wp + 4 * c + 128 * h);
+                            char* xrow = (char*)g.x16 + (size_t)prow * ((uint32_t)g.ldx16 * 2u);
+                            *(V4*)(xrow + pcol * 2u) = o;
+                            if (g.x8_off > 0) *(uint32_t*)(xrow + (uint32_t)g.x8_off + pcol) = pack_bf8x4(nv[0], nv[1], nv[2], nv[3]);
+                        } else {
+                            *(V4*)((char*)g.x16 + (off >> 1)) = o;
+                        }
                         float s1 = (nv[0] + nv[1]) + (nv[2] + nv[3]);
                         float s2 = (nv[0] * nv[0] + nv[1] * nv[1]) + (nv[2] * nv[2] + nv[3] * nv[3]);
                         s1 = row16_sum(s1);
@@ -514,22 +623,31 @@ int launch256_dt(const GemmArgs& g, hipStream_t s) {
     if (ncu <= 0) return MHMR_ERR_BAD_ARG;
     const int grid = ntiles < ncu ? ntiles : ncu;      // one persistent block per CU
     // 160 KiB of dynamic LDS: the attribute is per device (DeviceOnce, mhmr_internal.h)
-#define MHMR_GEMM_LAUNCH(E, F)                                                                                 \
+#define MHMR_GEMM_LAUNCH8(E, F, L8)                                                                            \
     {                                                                                                          \
         static DeviceOnce once;                                                                                \
         int dev = 0;                                                                                           \
         const int need = once.need(&dev);                                                                      \
         if (need == -2) return MHMR_ERR_BAD_ARG;                                                               \
         if (need >= 0) {                                                                                       \
-            hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DT, E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DT, E, F, L8>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                LDS_BYTES);                                                     \
             if (e != hipSuccess) return (int)e;                                                                \
             once.mark(dev);                                                                                    \
         }                                                                                                      \
-        hipLaunchKernelGGL((gemm256_kernel<DT, E, F>), dim3(grid), dim3(512), LDS_BYTES, s, g);                \
+        hipLaunchKernelGGL((gemm256_kernel<DT, E, F, L8>), dim3(grid), dim3(512), LDS_BYTES, s, g);            \
     }
+#define MHMR_GEMM_LAUNCH(E, F) MHMR_GEMM_LAUNCH8(E, F, false)
 #define MHMR_GEMM_CASE(E) \
     case E: MHMR_GEMM_LAUNCH(E, false) break;
+    if (g.lo8) {                            // fp8 low-half range: the V^T projection (plain or folded) and the residual projection
+        if (g.epi == EPI_VT && g.rowstats != nullptr) MHMR_GEMM_LAUNCH8(EPI_VT, true, true)
+        else if (g.epi == EPI_VT) MHMR_GEMM_LAUNCH8(EPI_VT, false, true)
+        else if (g.epi == EPI_RESID) MHMR_GEMM_LAUNCH8(EPI_RESID, false, true)
+        else return MHMR_ERR_BAD_ARG;
+        MHMR_CHECK_LAUNCH();
+        return 0;
+    }
     if (g.rowstats != nullptr) {            // consumers of a folded LayerNorm
         switch (g.epi) {
             case EPI_OP16_GELU: MHMR_GEMM_LAUNCH(EPI_OP16_GELU, true) break;
@@ -554,6 +672,7 @@ int launch256_dt(const GemmArgs& g, hipStream_t s) {
     }
 #undef MHMR_GEMM_CASE
 #undef MHMR_GEMM_LAUNCH
+#undef MHMR_GEMM_LAUNCH8
     MHMR_CHECK_LAUNCH();
     return 0;
 }
@@ -564,7 +683,9 @@ bool mhmr_gemm256_eligible(const GemmArgs& g) {
     const uint64_t mphys = g.img_rows > 0 ? (uint64_t)(g.M / g.img_rows) * (uint64_t)g.img_stride : (uint64_t)g.M;
     if (g.epi == EPI_RESID && mphys * (uint64_t)g.ldo * 4u >= (1ull << 32)) return false;   // 32-bit residual offsets
     if (g.img_rows > 0 && (g.img_rows % 256 || g.M % g.img_rows || g.epi == EPI_PATCH)) return false;   // a tile never straddles two images
-    if (g.a_k > 0 && (g.a_k % 128 || (g.K != 2 * g.a_k && g.K != 3 * g.a_k))) return false;
+    if (g.lo8) {       // fp8 low-half range: K = a_k + a_k / 2 (the low range as bytes), whole PAIRS of 128-deep fp8 tiles
+        if (g.a_k <= 0 || g.a_k % 256 || g.K != g.a_k + g.a_k / 2 || g.lda < g.K || g.ldw < g.K || !(g.epi == EPI_VT || g.epi == EPI_RESID)) return false;
+    } else if (g.a_k > 0 && (g.a_k % 128 || (g.K != 2 * g.a_k && g.K != 3 * g.a_k))) return false;
     if (g.lda >= (1 << 22) || g.ldw >= (1 << 22)) return false;      // 32-bit operand offsets INSIDE a 256-row tile (tile bases are 64-bit)
     return g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && (g.epi != EPI_VT || g.Tp % 64 == 0);
 }

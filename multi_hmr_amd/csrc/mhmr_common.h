@@ -77,6 +77,16 @@ template <> struct Op<MHMR_DT_F16> {
     }
 };
 
+// fp32 x4 -> four bf8 (e5m2) bytes, round to nearest even, clamped to the format's finite range first (+-57344)
+__device__ __forceinline__ uint32_t pack_bf8x4(float a, float b, float c, float d) {
+    const float lim = 57344.f;
+    a = __builtin_amdgcn_fmed3f(a, -lim, lim); b = __builtin_amdgcn_fmed3f(b, -lim, lim);
+    c = __builtin_amdgcn_fmed3f(c, -lim, lim); d = __builtin_amdgcn_fmed3f(d, -lim, lim);
+    int r = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
+    r = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, r, true);
+    return (uint32_t)r;
+}
+
 // C/D fragment of a 32x32 MFMA: lane l holds column (l & 31) and rows crow(r, l >> 5), r = 0..15.
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 

@@ -36,6 +36,16 @@ struct GemmArgs {
     // K = 3 * a_k (the f16x3 precision mode): W = [W_hi | W_lo | W_hi], A = [A_hi | A_lo] (lda >= 2 a_k): the k tiles of the third range
     // read the activation's SECOND a_k columns, so acc = A_hi W_hi^T + A_hi W_lo^T + A_lo W_hi^T -- three 16-bit products per term.
     int a_k = 0;
+    // fp8 low-half range (gemm256 only; the weight's LOW half needs three significant bits, not eleven).  lo8 != 0: BOTH operand rows are
+    // [a_k op16 values | a_k bytes of fp8] (lda, ldw >= K = a_k + a_k / 2 in 16-bit units), and the k tiles behind a_k are 128-deep fp8 tiles
+    // on v_mfma_scale_f32_16x16x128_f8f6f4 (twice the 16-bit rate) -- same 16 KiB half-tile slots, same copies, same fragment reads, no
+    // activation wrap-around: only the MFMA differs.  Weight bytes: e4m3 of W_lo * 2^-e with w8_scale = 127 + e (E8M0); activation bytes:
+    // bf8 (e5m2) of the SAME values as the 16-bit part, unscaled, written by the activation's producer (x8_off below; attention's out8).
+    int lo8 = 0;
+    int w8_scale = 127;
+    // producer side (EPI_RESID with x16): row pitch of x16 in elements (0 = ldo) and, if x8_off > 0, the byte offset inside an x16 row where
+    // the bf8 copy of the row's N values goes (the next linear's fp8 low-half range)
+    int ldx16 = 0, x8_off = 0;
     int colgroup = 0;        // gemm256: column-group tile order for wide outputs: log2 of the weight column panels an XCD keeps (2 = four panels, 3 = eight; 0 = off); set by mhmr_launch_gemm, MHMR_COLGROUP overrides
     // LayerNorm folded into the neighbouring GEMMs (gemm256 only): the LayerNorm pass of its own disappears.
     //   producer (EPI_RESID): besides the fp32 residual rows it writes x16 = their 16-bit copy (RAW, un-normalised: the next linear's A

@@ -65,7 +65,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <int DT, int NP, int VEC, bool FINAL, bool PAIR = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, const float* __restrict__ gw,
                                                         const float* __restrict__ gb, void* __restrict__ out16_, int ld16,
-                                                        float* __restrict__ out32, int rows, int Np, int Tp, float eps) {
+                                                        float* __restrict__ out32, int rows, int Np, int Tp, float eps, int o8) {
+    // o8 > 0 (VEC == 4 only): byte offset inside an out16 row where the bf8 (e5m2) copy of the row goes (the fp8 low-half range of the next linear)
     typedef typename Op<DT>::T T;
     typedef float fv __attribute__((ext_vector_type(VEC)));
     typedef T hv __attribute__((ext_vector_type(VEC)));
@@ -113,6 +114,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         }
         *(hv*)(o16 + c) = h;
         if constexpr (PAIR) *(hv*)(o16 + C + c) = hl;
+        if constexpr (VEC == 4 && !PAIR && !FINAL) {
+            if (o8 > 0) *(uint32_t*)((char*)o16 + o8 + c) = pack_bf8x4(y[0], y[1], y[2], y[3]);
+        }
         if constexpr (FINAL) *(fv*)(out32 + out_row * C + c) = y;
     }
 }
@@ -190,12 +194,13 @@ __global__ __launch_bounds__(256) void gelu_pair_kernel(const float* __restrict_
 
 template <int DT, bool FINAL, bool PAIR = false>
 int launch_ln(const float* in, const float* w, const float* b, void* out16, int ld16, float* out32, int rows, int C,
-              int Np, int Tp, float eps, hipStream_t s) {
+              int Np, int Tp, float eps, hipStream_t s, int o8 = 0) {
+    if (o8 > 0 && (C % 256 || o8 < 2 * C || o8 + C > 2 * ld16)) return MHMR_ERR_BAD_ARG;
     const int grid = (rows + 3) / 4;
 #define LN_CASE(CV, NPV, VECV)                                                                                           \
     case CV:                                                                                                             \
         hipLaunchKernelGGL((layernorm_kernel<DT, NPV, VECV, FINAL, PAIR>), dim3(grid), dim3(256), 0, s, in, w, b, out16, ld16, out32, \
-                           rows, Np, Tp, eps);                                                                           \
+                           rows, Np, Tp, eps, o8);                                                                       \
         break;
     switch (C) {
         LN_CASE(384, 3, 2)
@@ -259,6 +264,14 @@ int mhmr_launch_layernorm(const float* in, const float* w, const float* b, void*
                           int dtype, hipStream_t s) {
     return dtype == MHMR_DT_F16 ? launch_ln<MHMR_DT_F16, false>(in, w, b, out16, C, nullptr, rows, C, 0, 0, eps, s)
                                 : launch_ln<MHMR_DT_BF16, false>(in, w, b, out16, C, nullptr, rows, C, 0, 0, eps, s);
+}
+
+// the same into rows of pitch ld16 (elements), optionally with the bf8 copy of each row at byte offset o8 (0 = none)
+int mhmr_launch_layernorm_pitch(const float* in, const float* w, const float* b, void* out16, int ld16, int o8, int rows, int C, float eps,
+                                int dtype, hipStream_t s) {
+    if (ld16 < C) return MHMR_ERR_BAD_ARG;
+    return dtype == MHMR_DT_F16 ? launch_ln<MHMR_DT_F16, false>(in, w, b, out16, ld16, nullptr, rows, C, 0, 0, eps, s, o8)
+                                : launch_ln<MHMR_DT_BF16, false>(in, w, b, out16, ld16, nullptr, rows, C, 0, 0, eps, s, o8);
 }
 
 int mhmr_launch_ln_stats(const float* pstats, const float* resid, float* rowstats, int B, int N, int Tp, int C, float eps, hipStream_t s) {

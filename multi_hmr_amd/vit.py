@@ -7,6 +7,7 @@ lookup.
 from __future__ import annotations
 
 import ctypes as C
+import math
 
 import torch
 
@@ -97,6 +98,27 @@ def triple(w: torch.Tensor, tdt) -> torch.Tensor:
     return torch.cat([hi, lo, hi], dim=1).contiguous()
 
 
+def lo8_rows(w_hi16: torch.Tensor, w32: torch.Tensor):
+    """One linear's weight with an fp8 low-half range (csrc/gemm256.hip GemmArgs::lo8): rows of 3K bytes = [W_hi: K 16-bit values |
+    e4m3(W_lo * 2^-e): K bytes], W_lo = W - W_hi, and the E8M0 scale byte 127 + e.  e puts the largest |W_lo| at <= 256 (e4m3: three
+    significant bits down to 2^-6, finite to 448), i.e. the low half is kept to three bits -- 2^-15 of the weight instead of 2^-12.
+    Returns (uint8 [N, 3K], scale byte, the dequantised low half as fp64 [N, K] -- for the folded linears' column sums)."""
+    lo = (w32.double() - w_hi16.double())
+    amax = float(lo.abs().max())
+    e = (math.ceil(math.log2(amax)) - 8) if amax > 0 else -127
+    e = max(min(e, 127), -127)
+    q = (lo * 2.0 ** (-e)).float().to(torch.float8_e4m3fn)
+    rows = torch.cat([w_hi16.contiguous().view(torch.uint8).reshape(w_hi16.shape[0], -1), q.view(torch.uint8)], dim=1).contiguous()
+    return rows, 127 + e, q.double() * 2.0 ** e
+
+
+def lo8_eligible(C: int) -> bool:
+    """fp8 low-half ranges need the 256x256 kernel's 128-deep fp8 k tiles in whole pairs: embed_dim a multiple of 256 (ViT-B / ViT-L).
+    MHMR_LO8=0 switches them off (the 16-bit low halves run instead: A/B measurements)."""
+    import os
+    return C % 256 == 0 and os.environ.get("MHMR_LO8", "1") != "0" and "MHMR_GEMM128" not in os.environ
+
+
 def fold_eligible(C: int, N: int) -> bool:
     """The LayerNorm fold (csrc/gemm256.hip, GemmArgs::pstats / rowstats) needs every block linear on the 256x256 kernel: embed_dim a
     multiple of 256 (ViT-B / ViT-L), and either the token-row map (N a multiple of 256) or, for any other N (1288^2: 8464), the rows
@@ -165,18 +187,26 @@ def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = N
     if P["fold"] and Cd % 256:
         raise ValueError("lnfold needs embed_dim to be a multiple of 256")
 
+    P["lo8"] = lo8_eligible(Cd) and bool(lo_passes)
+
     def folded(lin, norm, lo_rows=None):
-        """-> (op16 W' [N, K], fp32 b' [N], fp32 colsum [N], hi|lo of rows lo_rows or None)"""
+        """-> (op16 W' [N, K], fp32 b' [N], fp32 colsum [N], hi|lo of rows lo_rows or None, their fp8 form (rows, scale) or None)"""
         W, lw, lb = f32(lin.weight).double(), f32(norm.weight).double(), f32(norm.bias).double()
         Wf = (W * lw[None, :]).float()
         bias = (f32(lin.bias).double() + W @ lb).float()
         W16 = Wf.to(tdt)
         colsum = W16.double().sum(1)
-        w2 = None
+        w2 = w8 = None
         if lo_rows is not None:
             w2 = hi_lo(Wf[lo_rows], tdt)
             colsum[lo_rows] = w2.double().sum(1)
-        return W16.contiguous(), bias.contiguous(), colsum.float().contiguous(), w2
+            if P["lo8"]:
+                # the big GEMM multiplies the e4m3 low half: the column sums are over exactly those values (the class-row kernel keeps the
+                # 16-bit low half: its sum differs by the e4m3 rounding of W_lo, ~2^-16 of a weight -- far below the row statistics' own rounding)
+                rows8, sc, lo_deq = lo8_rows(W16[lo_rows], Wf[lo_rows])
+                colsum[lo_rows] = W16[lo_rows].double().sum(1) + lo_deq.sum(1)
+                w8 = (rows8, sc)
+        return W16.contiguous(), bias.contiguous(), colsum.float().contiguous(), w2, w8
 
     for i, b in enumerate(enc.blocks):
         blk = blocks[i]
@@ -184,18 +214,29 @@ def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = N
         v_rows = slice(2 * Cd, 3 * Cd)
         blk.flags = (1 if f1 else 0) | (2 if f2 else 0)
         blk.proj_w2 = k(hi_lo(f32(b.attn.proj.weight), tdt)) if "proj" in lo_passes.get(i, ()) else None
+        blk.v_w8, blk.proj_w8, blk.v_w8_scale, blk.proj_w8_scale = None, None, 127, 127
+        if P["lo8"] and "proj" in lo_passes.get(i, ()):
+            pw32 = f32(b.attn.proj.weight)
+            rows8, blk.proj_w8_scale, _ = lo8_rows(pw32.to(tdt), pw32)
+            blk.proj_w8 = k(rows8)
         blk.ln1_w, blk.ln1_b = k(f32(b.norm1.weight)), k(f32(b.norm1.bias))
         if f1:
-            w16, bias, colsum, v2 = folded(b.attn.qkv, b.norm1, v_rows if "v" in lo_passes.get(i, ()) else None)
+            w16, bias, colsum, v2, v8 = folded(b.attn.qkv, b.norm1, v_rows if "v" in lo_passes.get(i, ()) else None)
             blk.qkv_w, blk.qkv_b, blk.qkv_colsum = k(w16), k(bias), k(colsum)
             blk.v_w2 = k(v2) if v2 is not None else None
+            if v8 is not None:
+                blk.v_w8, blk.v_w8_scale = k(v8[0]), v8[1]
         else:
             blk.qkv_w, blk.qkv_b, blk.qkv_colsum = k(op(b.attn.qkv.weight)), k(f32(b.attn.qkv.bias)), None
             blk.v_w2 = k(hi_lo(f32(b.attn.qkv.weight)[v_rows], tdt)) if "v" in lo_passes.get(i, ()) else None
+            if P["lo8"] and "v" in lo_passes.get(i, ()):
+                vw32 = f32(b.attn.qkv.weight)[v_rows]
+                rows8, blk.v_w8_scale, _ = lo8_rows(vw32.to(tdt), vw32)
+                blk.v_w8 = k(rows8)
         blk.proj_w, blk.proj_b, blk.ls1 = k(op(b.attn.proj.weight)), k(f32(b.attn.proj.bias)), k(f32(b.ls1.gamma))
         blk.ln2_w, blk.ln2_b = k(f32(b.norm2.weight)), k(f32(b.norm2.bias))
         if f2:
-            w16, bias, colsum, _ = folded(b.mlp.fc1, b.norm2)
+            w16, bias, colsum, _, _ = folded(b.mlp.fc1, b.norm2)
             blk.fc1_w, blk.fc1_b, blk.fc1_colsum = k(w16), k(bias), k(colsum)
         else:
             blk.fc1_w, blk.fc1_b, blk.fc1_colsum = k(op(b.mlp.fc1.weight)), k(f32(b.mlp.fc1.bias)), None
@@ -276,8 +317,9 @@ class WorkspaceCache:
                 b = dict(a_patch=z(Mp, 2 * P["Kp"]), resid=z(Bh * Tp, Cd, dtype=torch.float32), xn=z(Bh * Tp, 2 * Cd), att=z(Bh * Tp, 2 * Cd),
                          hid=z(Bh * Tp, 8 * Cd), qkv32=z(Bh * Tp, 3 * Cd, dtype=torch.float32), hid32=z(Bh * Tp, 4 * Cd, dtype=torch.float32))
             else:
-                b = dict(a_patch=z(Mp, P["Kp"]), resid=z(Bh * Tp, Cd, dtype=torch.float32), xn=z(Bh * Tp, Cd), qk=z(Bh * Tp, 2 * Cd),
-                         vt=z(Bh * H * 64, Tp), att=z(Bh * Tp, Cd), hid=z(Bh * Tp, 4 * Cd),
+                pit = Cd + Cd // 2 if P.get("lo8") else Cd       # lo8: a row of xn / att carries its bf8 copy behind its C values
+                b = dict(a_patch=z(Mp, P["Kp"]), resid=z(Bh * Tp, Cd, dtype=torch.float32), xn=z(Bh * Tp, pit), qk=z(Bh * Tp, 2 * Cd),
+                         vt=z(Bh * H * 64, Tp), att=z(Bh * Tp, pit), hid=z(Bh * Tp, 4 * Cd),
                          attn_flags=z(_lib.lib().mhmr_attention_flag_count(Bh, Tp, H), dtype=torch.int32))
             if P.get("fold"):
                 b.update(pstats=z(Bh * Tp, Cd // 64, 2, dtype=torch.float32), rowstats=z(Bh * Tp, 2, dtype=torch.float32))
@@ -290,6 +332,7 @@ class WorkspaceCache:
             for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid", "attn_flags", "qkv32", "hid32"):
                 setattr(d, n, b[n].data_ptr() if n in b else None)
             d.x3 = 1 if x3 else 0
+            d.lo8 = 1 if (P.get("lo8") and not x3) else 0
             d.pstats = b["pstats"].data_ptr() if P.get("fold") else None
             d.rowstats = b["rowstats"].data_ptr() if P.get("fold") else None
             parts.append(dict(desc=d, B=Bh, img0=i * Bh, bufs=b))

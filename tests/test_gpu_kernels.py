@@ -734,3 +734,112 @@ def test_attention_is_bit_reproducible(L):
         if ref is None:
             ref = out
         assert torch.equal(ref, out)
+
+
+# ---------------------------------------------------------------------------------------------------------------- fp8 low-half range (round 5)
+def _lo8_operands(M, N, K, seed, hot=True):
+    from multi_hmr_amd import vit
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    A32 = torch.randn(M, K, generator=g)
+    if hot:
+        A32[:, 5] *= 60.0                       # a massive-activation channel: bf8 (e5m2) has the range for it
+    W32 = torch.randn(N, K, generator=g) * 0.03
+    A16 = A32.half()
+    A8 = A32.to(torch.float8_e5m2)
+    Arow = torch.cat([A16.view(torch.uint8).reshape(M, 2 * K), A8.view(torch.uint8)], 1).contiguous()          # [M, 3K] bytes
+    W16 = W32.half()
+    Wrow, scale, lo_deq = vit.lo8_rows(W16, W32)                                                                 # [N, 3K] bytes
+    exact = A16.double() @ W32.double().T                                              # what the low half is for: the UNROUNDED weight
+    emul = A16.double() @ W16.double().T + A8.double() @ lo_deq.T                      # what the kernel computes, term by term
+    return A32, W32, Arow.to(dev()), Wrow.to(dev()), scale, exact.to(dev()), emul.to(dev()), A16.to(dev()), W16.to(dev())
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (512, 256, 1024), (256, 512, 768)])
+def test_gemm_fp8_low_half_range(L, M, N, K):
+    """GemmArgs::lo8 (csrc/gemm256.hip): operand rows [K 16-bit values | K bytes fp8]; the k tiles behind K run on
+    v_mfma_scale_f32_16x16x128_f8f6f4 (weight: e4m3 x 2^e, activation: e5m2).  Against the term-by-term emulation (fp64) the kernel is
+    exact to fp32 accumulation -- layout, formats, the E8M0 scale and the k permutation of the fragments all have to be right for that --
+    and against the unrounded weights the error is several times below a single f16 pass (the low half kept to three bits)."""
+    A32, W32, Arow, Wrow, scale, exact, emul, A16, W16 = _lo8_operands(M, N, K, M + N + K)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(1)).to(dev())
+    gamma = (0.5 + torch.rand(N, generator=torch.Generator().manual_seed(2))).to(dev())
+    # residual epilogue, with the producer outputs in a pitched x16 (+ its bf8 copy) and the block sums
+    r0 = torch.randn(M, N, generator=torch.Generator().manual_seed(3)).to(dev())
+    out = r0.clone()
+    pit = N + N // 2
+    x16 = torch.zeros(M, pit, dtype=torch.float16, device=dev())
+    pstats = torch.zeros(M, N // 64, 2, device=dev())
+    _lib.check(L.mhmr_gemm16_lo8(Arow.data_ptr(), K + K // 2, Wrow.data_ptr(), K + K // 2, M, N, K, 1, scale, bias.data_ptr(), gamma.data_ptr(),
+                                 out.data_ptr(), N, 128, 1, _lib.EPI_RESID, _lib.DT_F16, 0, 0, x16.data_ptr(), pit, 2 * N, pstats.data_ptr(), None, None,
+                                 None, stream()), "gemm lo8 resid")
+    got = (out.double() - r0.double()) / gamma.double() - bias.double()
+    e_emul, e_exact = rel(got, emul), rel(got, exact)
+    one = A16.double() @ W16.double().T
+    e_one = rel(one, exact)
+    assert e_emul < 2e-5, e_emul                                    # (read back through out - r0: fp32 cancellation)
+    assert e_one > 1e-4 and e_exact < e_one / 4, (e_exact, e_one)
+    # producer outputs: the 16-bit copy of the new rows, their bf8 copy behind it, the per-64-column sums
+    assert torch.equal(x16[:, :N], out.half())
+    x8 = x16.view(torch.uint8).reshape(M, 2 * pit)[:, 2 * N:3 * N].contiguous().view(torch.float8_e5m2)
+    want8 = out.to(torch.float8_e5m2)
+    assert float((x8.view(torch.uint8) == want8.view(torch.uint8)).float().mean()) > 0.999
+    assert float((x8.float() - out).abs().max() / out.abs().max()) < 0.13
+    s1 = out.double().view(M, N // 64, 64).sum(-1)
+    assert rel(pstats[..., 0].double(), s1) < 1e-5
+    # V^T epilogue (the activation is the FIRST operand there), plain and with the folded LayerNorm
+    if M % 128 == 0 and N % 64 == 0:
+        B, H, Tp = 1, N // 64, M
+        perm = swap23(torch.arange(Tp, device=dev()))
+        vt = torch.zeros(B, H, 64, Tp, dtype=torch.float16, device=dev())
+        _lib.check(L.mhmr_gemm16_lo8(Arow.data_ptr(), K + K // 2, Wrow.data_ptr(), K + K // 2, M, N, K, 1, scale, bias.data_ptr(), None, vt.data_ptr(), 0,
+                                     Tp, H, _lib.EPI_VT, _lib.DT_F16, 0, 0, None, 0, 0, None, None, None, None, stream()), "gemm lo8 vt")
+        ref = (emul + bias.double()).float().view(B, Tp, H, 64).permute(0, 2, 3, 1)
+        assert maxrel(vt.float()[..., perm], ref) < 2e-3
+        mean = A16.double().mean(1)
+        rstd = 1.0 / (A16.double().var(1, unbiased=False) + 1e-6).sqrt()
+        rowstats = torch.stack([mean, rstd], 1).float().contiguous()
+        colsum = (W16.double().sum(1) + (emul - A16.double() @ W16.double().T).sum(0) * 0).float()       # placeholder shape; real sum below
+        lo_deq = (Wrow[:, 2 * K:].contiguous().view(torch.float8_e4m3fn).double() * 2.0 ** (scale - 127))
+        colsum = (W16.double().sum(1) + lo_deq.sum(1)).float().contiguous()
+        vt2 = torch.zeros_like(vt)
+        _lib.check(L.mhmr_gemm16_lo8(Arow.data_ptr(), K + K // 2, Wrow.data_ptr(), K + K // 2, M, N, K, 1, scale, None, None, vt2.data_ptr(), 0, Tp, H,
+                                     _lib.EPI_VT, _lib.DT_F16, 0, 0, None, 0, 0, None, rowstats.data_ptr(), colsum.data_ptr(), bias.data_ptr(), stream()),
+                   "gemm lo8 vt fold")
+        ref2 = (rstd[:, None] * (emul - mean[:, None] * colsum.double()[None, :]) + bias.double()).float().view(B, Tp, H, 64).permute(0, 2, 3, 1)
+        assert maxrel(vt2.float()[..., perm], ref2) < 3e-3
+
+
+def test_attention_and_layernorm_with_a_row_pitch_and_the_bf8_copy(L):
+    """The producers of the fp8 low-half range's activation bytes: attention (variant 6) and the LayerNorm kernel write rows of 3C/2
+    elements -- C 16-bit values, bit-identical to the plain form, and behind them the bf8 (e5m2) copy of the same values."""
+    B, H, T = 2, 4, 321
+    C, Tp = 64 * H, 384
+    pit = C + C // 2
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    qk = (torch.randn(B * Tp, 2 * C, device=dev(), generator=g) * 0.5).half()
+    vt = (torch.randn(B * H * 64, Tp, device=dev(), generator=g) * 0.5).half()
+    nfl = L.mhmr_attention_flag_count(B, Tp, H)
+    flags = torch.zeros(nfl, dtype=torch.int32, device=dev())
+    plain = torch.zeros(B * Tp, C, dtype=torch.float16, device=dev())
+    _lib.check(L.mhmr_attention16_ex(qk.data_ptr(), vt.data_ptr(), plain.data_ptr(), B, T, Tp, C, H, _lib.DT_F16, 15.0, 6, flags.data_ptr(), stream()), "attn")
+    wide = torch.zeros(B * Tp, pit, dtype=torch.float16, device=dev())
+    _lib.check(L.mhmr_attention16_pitch(qk.data_ptr(), vt.data_ptr(), wide.data_ptr(), B, T, Tp, C, H, _lib.DT_F16, flags.data_ptr(), pit, 2 * C, stream()), "attn pitch")
+    assert torch.equal(wide[:, :C], plain)
+    a8 = wide.view(torch.uint8).reshape(B * Tp, 2 * pit)[:, 2 * C:3 * C].contiguous().view(torch.float8_e5m2).float()
+    real = torch.arange(B * Tp, device=dev()) % Tp < T
+    err = (a8[real] - plain[real].float()).abs()
+    assert float((err <= 0.126 * plain[real].float().abs() + 1e-4).float().mean()) == 1.0
+    assert float(a8[real].abs().max()) > 0
+    # LayerNorm
+    rows, Cl = 200, 768
+    x = (torch.randn(rows, Cl, device=dev(), generator=g) * 2 + 0.7)
+    w, b = torch.rand(Cl, device=dev(), generator=g) + 0.5, torch.randn(Cl, device=dev(), generator=g)
+    p2 = Cl + Cl // 2
+    o1 = torch.zeros(rows, Cl, dtype=torch.float16, device=dev())
+    o2 = torch.zeros(rows, p2, dtype=torch.float16, device=dev())
+    _lib.check(L.mhmr_layernorm16(x.data_ptr(), w.data_ptr(), b.data_ptr(), o1.data_ptr(), rows, Cl, 1e-6, _lib.DT_F16, stream()), "ln")
+    _lib.check(L.mhmr_layernorm16_pitch(x.data_ptr(), w.data_ptr(), b.data_ptr(), o2.data_ptr(), p2, 2 * Cl, rows, Cl, 1e-6, _lib.DT_F16, stream()), "ln pitch")
+    assert torch.equal(o2[:, :Cl], o1)
+    y8 = o2.view(torch.uint8).reshape(rows, 2 * p2)[:, 2 * Cl:3 * Cl].contiguous().view(torch.float8_e5m2).float()
+    ref = torch.nn.functional.layer_norm(x, (Cl,), w, b, 1e-6)
+    assert float(((y8 - ref).abs() <= 0.126 * ref.abs() + 1e-4).float().mean()) == 1.0

@@ -230,10 +230,20 @@ def test_layernorm_fold_packing_is_the_same_linear_map():
             err = float((got[:, rows] - want[:, rows]).abs().max() / want.abs().max())
             assert err < 2e-3, (i, err)                                               # one f16 rounding of W'
     v2, cs = by_ptr[blocks[1].v_w2].double(), by_ptr[blocks[1].qkv_colsum].double()[512:]
-    assert v2.shape == (256, 512) and torch.allclose(cs, v2.sum(1), atol=1e-6)
     b = enc.blocks[1].double()
     want = b.attn.qkv(b.norm1(x))[:, 512:]
-    got = rstd * (torch.cat([x, x], 1) @ v2.T - mean * cs[None, :]) + by_ptr[blocks[1].qkv_b].double()[None, 512:]
+    assert v2.shape == (256, 512) and P["lo8"] and blocks[1].v_w8 and not blocks[1].proj_w8 and not blocks[0].v_w8
+    # embed_dim 256 is eligible for the fp8 low-half range: the big GEMM multiplies [W'_hi | e4m3(W'_lo 2^-e)] and the column sums count
+    # exactly those values; the 16-bit pair (what the class-row kernel multiplies) sums to the same within the e4m3 rounding of W'_lo
+    rows8 = by_ptr[blocks[1].v_w8]
+    assert rows8.dtype == torch.uint8 and rows8.shape == (256, 3 * 256)
+    hi = rows8[:, :512].contiguous().view(torch.float16).double()
+    lo = rows8[:, 512:].contiguous().view(torch.float8_e4m3fn).double() * 2.0 ** (blocks[1].v_w8_scale - 127)
+    assert torch.equal(hi, v2[:, :256]) and torch.allclose(cs, (hi + lo).sum(1), atol=1e-6) and torch.allclose(cs, v2.sum(1), atol=2e-5)
+    assert float((lo - v2[:, 256:]).abs().max()) <= 2.0 ** -4 * float(v2[:, 256:].abs().max()) + 1e-12      # three significant bits of W'_lo
+    got8 = rstd * (x @ (hi + lo).T - mean * cs[None, :]) + by_ptr[blocks[1].qkv_b].double()[None, 512:]
+    assert float((got8 - want).abs().max() / want.abs().max()) < 3e-5                  # hi + e4m3 lo: ~15 bits of the weight
+    got = rstd * (torch.cat([x, x], 1) @ v2.T - mean * v2.sum(1)[None, :]) + by_ptr[blocks[1].qkv_b].double()[None, 512:]
     assert float((got - want).abs().max() / want.abs().max()) < 2e-6                   # hi + lo: 22 bits
     torch.set_grad_enabled(True)
 
