@@ -114,9 +114,13 @@ def lo8_rows(w_hi16: torch.Tensor, w32: torch.Tensor):
 
 def lo8_eligible(C: int) -> bool:
     """fp8 low-half ranges need the 256x256 kernel's 128-deep fp8 k tiles in whole pairs: embed_dim a multiple of 256 (ViT-B / ViT-L).
-    MHMR_LO8=0 switches them off (the 16-bit low halves run instead: A/B measurements)."""
+    OFF unless MHMR_LO8=1: built, parity-green (tests/test_gpu_kernels.py::test_gemm_fp8_low_half_range, the full-size goldens) and
+    measured SLOWER than the 16-bit low halves on this power-clocked chip -- 135.8 vs 133.6 ms per headline step, interleaved on one box
+    (profiles/r05_session_d_fp8_low_half_ab.txt, r05_session_e_lo8_kernel_trace.txt): the fp8 k tiles, nominally twice the rate, took
+    as long as the 16-bit tiles they replaced (V 425 vs ~443 us, proj 569 vs ~513 us), and the 3C/2 row pitch the bf8 copies need cost
+    every other consumer of those rows (fc1 +28 us, QK +17 us, attention +28 us per launch)."""
     import os
-    return C % 256 == 0 and os.environ.get("MHMR_LO8", "1") != "0" and "MHMR_GEMM128" not in os.environ
+    return C % 256 == 0 and os.environ.get("MHMR_LO8", "0") == "1" and "MHMR_GEMM128" not in os.environ
 
 
 def fold_eligible(C: int, N: int) -> bool:

@@ -197,7 +197,7 @@ def test_low_half_weight_split_and_spec_parser():
         vit.parse_wlo("fc1@0-3", 24)
 
 
-def test_layernorm_fold_packing_is_the_same_linear_map():
+def test_layernorm_fold_packing_is_the_same_linear_map(monkeypatch):
     """vit.pack_encoder(lnfold=True) on the CPU: for a folded linear, rstd (x . W'^T - mean colsum) + b' computed in fp64 from the PACKED
     tensors equals Linear(LayerNorm(x)) up to the 16-bit rounding of W' (reference blocks/dinov2.py -> hub Block: norm1 -> attn.qkv,
     norm2 -> mlp.fc1); block 0's norm1 is not folded; the V rows with a low half carry [W'_hi | W'_lo] and their colsum counts both."""
@@ -206,6 +206,7 @@ def test_layernorm_fold_packing_is_the_same_linear_map():
     from oracle import dinov2_ref
     from multi_hmr_amd import vit
     torch.manual_seed(5)
+    monkeypatch.setenv("MHMR_LO8", "1")                              # also pack the fp8 form of the low halves (opt-in: vit.lo8_eligible)
     enc = dinov2_ref.DinoVisionTransformer(embed_dim=256, depth=3, num_heads=4).double()
     for b in enc.blocks:                                             # non-trivial LayerNorm parameters
         for n in (b.norm1, b.norm2):
