@@ -198,11 +198,17 @@ def main():
     ap.add_argument("--persons", type=int, default=8, help="pinned detections per image")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (cpu_baseline AND parity)")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline side measurements, the other configs and the other precision")
+    ap.add_argument("--only-latency", action="store_true", help="print the latency_b1 object alone (A/B sessions)")
     ap.add_argument("--only-headline-kernels", action="store_true",
                     help="profiling runs (rocprofv3 --pmc): the headline forward and its roofline passes only, so that per-kernel "
                          "averages are not mixed with the other configurations' shapes")
     args = ap.parse_args()
 
+    if args.only_latency:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        print(json.dumps(latency_b1(args.dtype, synthetic.make_smplx_data(0), synthetic.make_mean_params(0), dev)))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))

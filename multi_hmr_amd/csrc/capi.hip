@@ -282,7 +282,9 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
     // otherwise one GEMM covers all B * Tp rows.  MHMR_ROWMAP=0 forces the latter (A/B measurements).  Everything is launched on the
     // caller's stream: the call is re-entrant across streams and capturable.
     static const bool rowmap_env = !(getenv("MHMR_ROWMAP") && atoi(getenv("MHMR_ROWMAP")) == 0) && !getenv("MHMR_GEMM128");
-    const bool rowmap = rowmap_env && C % 256 == 0 && N % 256 == 0 && (uint64_t)M * (uint64_t)C * 4u < (1ull << 32);
+    // (Tp a multiple of 256 where N is one too -- the row map's own padding is N + 64 -- is the caller saying "all rows": multi_hmr_amd/vit.py
+    // pads tiny batches that way, whose launches are latency-bound and not worth six class-row launches per block)
+    const bool rowmap = rowmap_env && C % 256 == 0 && N % 256 == 0 && Tp % 256 != 0 && (uint64_t)M * (uint64_t)C * 4u < (1ull << 32);
     const int Mg = rowmap ? B * N : M, ir = rowmap ? N : 0, is = rowmap ? Tp : 0;
     const size_t esz = 2;
     const long long cls_row = (long long)N;                          // the class row inside an image

@@ -252,13 +252,22 @@ def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = N
     return P
 
 
+def tiny_batch(P: dict, B: int) -> bool:
+    """The narrowest block linear (N = embed_dim) of the whole batch is at most HALF a round of 256x256 tiles on the chip (896^2: one
+    image; 672^2: up to three).  Such a launch is latency, not throughput: exact tile rounds buy nothing, while the class-row kernels the
+    token-row map needs are six more launches per block (~25 % of a batch-1 forward together with the row statistics)."""
+    return P["C"] % 256 == 0 and (B * roundup(P["T"], 256) // 256) * (P["C"] // 256) <= 128
+
+
 def row_map(P: dict, B: int) -> bool:
     """Mirror of the rule in csrc/capi.hip (mhmr_vit_forward): the five big GEMMs of a block run over the B * N patch rows only (the
-    class rows through csrc/vit_cls.hip) when an image's patch rows are whole 256-row tiles of the 256x256 kernel."""
+    class rows through csrc/vit_cls.hip) when an image's patch rows are whole 256-row tiles of the 256x256 kernel -- except for tiny
+    batches with folded LayerNorms, which run ALL rows (class and padding rows included, Tp a multiple of 256: that is how capi.hip tells)
+    through the big GEMMs and launch no class-row kernel at all."""
     import os
     T = P["T"]
     return (not P.get("x3") and os.environ.get("MHMR_ROWMAP", "1") != "0" and "MHMR_GEMM128" not in os.environ and P["C"] % 256 == 0 and (T - 1) % 256 == 0 and
-            B * roundup(T, 64) * P["C"] * 4 < 2 ** 32)
+            B * roundup(T, 64) * P["C"] * 4 < 2 ** 32 and not (P.get("fold") and tiny_batch(P, B) and os.environ.get("MHMR_TINY_ALLROWS", "1") != "0"))
 
 
 def padded_tokens(P: dict, B: int) -> int:
@@ -269,7 +278,8 @@ def padded_tokens(P: dict, B: int) -> int:
     import os
     if P.get("x3"):
         return roundup(P["T"], 256 if P["C"] % 256 == 0 else 128)      # all rows through every linear: whole tiles for every batch size
-    if P.get("fold") and (P["T"] - 1) % 256:
+    if P.get("fold") and ((P["T"] - 1) % 256 or (not row_map(P, B) and tiny_batch(P, B) and os.environ.get("MHMR_ROWMAP", "1") != "0" and
+                                              "MHMR_GEMM128" not in os.environ)):
         return roundup(P["T"], 256)        # folded LayerNorms without the row map: whole 256-row tiles of all rows, for every batch size
     t64, t128 = roundup(P["T"], 64), roundup(P["T"], 128)
     # the predicate of csrc/gemm256.hip mhmr_gemm256_eligible for the residual GEMMs over all B * Tp rows (32-bit residual offsets),

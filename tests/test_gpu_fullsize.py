@@ -30,14 +30,16 @@ def test_vitl_896_batch_invariance_and_determinism(model_896):
         assert torch.equal(a[k], b[k]), k                              # bit-exact run to run
         assert torch.isfinite(a[k]).all(), k
     assert a["v3d"].shape == (15, 10475, 3) and a["scores"].shape == (3, 64, 64, 1)
-    # image 1 alone == image 1 inside the batch (same rows, same accumulation order)
+    # image 1 alone == image 1 inside the batch: same patch rows, same accumulation order.  (Since round 5 a single 896^2 image is a "tiny
+    # batch": its class row runs through the big GEMM instead of the class-row kernel -- another summation order for that ONE row, which
+    # every token then attends to: agreement to fp32 rounding, 1e-5, no longer to the last bit.)
     sel = idx[0] == 1
     idx1 = (torch.zeros(int(sel.sum()), dtype=torch.long, device="cuda:0"), idx[1][sel], idx[2][sel], idx[3][sel])
     c = model_896(x[1:2], idx=idx1, K=K[1:2], is_training=True)
     for k in ("v3d", "rotmat", "transl", "shape", "expression", "loc"):
         d = (c[k] - a[k][sel]).abs().max() / a[k][sel].abs().max()
-        assert float(d) < 1e-6, (k, float(d))
-    assert float((c["scores"][0] - a["scores"][1]).abs().max()) < 1e-6
+        assert float(d) < 2e-5, (k, float(d))
+    assert float((c["scores"][0] - a["scores"][1]).abs().max()) < 2e-5
 
 
 def test_lbs_160_persons_linear_in_betas_at_zero_pose(smplx_data):
