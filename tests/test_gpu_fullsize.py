@@ -19,7 +19,7 @@ def model_896(smplx_data, mean_params):
     return m.to("cuda:0").eval()
 
 
-def test_vitl_896_batch_invariance_and_determinism(model_896):
+def test_vitl_896_batch_invariance_and_determinism(model_896, monkeypatch):
     g = torch.Generator(device="cuda:0").manual_seed(3)
     x = torch.randn(3, 3, 896, 896, generator=g, device="cuda:0")
     K = synthetic.get_camera_K(896, 3).cuda()
@@ -30,16 +30,26 @@ def test_vitl_896_batch_invariance_and_determinism(model_896):
         assert torch.equal(a[k], b[k]), k                              # bit-exact run to run
         assert torch.isfinite(a[k]).all(), k
     assert a["v3d"].shape == (15, 10475, 3) and a["scores"].shape == (3, 64, 64, 1)
-    # image 1 alone == image 1 inside the batch: same patch rows, same accumulation order.  (Since round 5 a single 896^2 image is a "tiny
-    # batch": its class row runs through the big GEMM instead of the class-row kernel -- another summation order for that ONE row, which
-    # every token then attends to: agreement to fp32 rounding, 1e-5, no longer to the last bit.)
     sel = idx[0] == 1
     idx1 = (torch.zeros(int(sel.sum()), dtype=torch.long, device="cuda:0"), idx[1][sel], idx[2][sel], idx[3][sel])
+    a_sel = {k: a[k][sel].clone() for k in ("v3d", "rotmat", "transl", "shape", "expression", "loc")}
+    a_scores = a["scores"][1].clone()
+    # Since round 5 ONE 896^2 image is a "tiny batch" (vit.tiny_batch): its class row runs through the big GEMMs instead of the class-row
+    # kernel -- another fp32 summation order for that one row, which every token attends to, and in a 16-bit pipeline a 1e-6 perturbation
+    # flips roundings downstream: image 1 alone then agrees with image 1 inside the batch to the 16-bit noise level (measured 1.3e-4 on
+    # v3d in the max norm), not to the last bit ...
     c = model_896(x[1:2], idx=idx1, K=K[1:2], is_training=True)
-    for k in ("v3d", "rotmat", "transl", "shape", "expression", "loc"):
-        d = (c[k] - a[k][sel]).abs().max() / a[k][sel].abs().max()
-        assert float(d) < 2e-5, (k, float(d))
-    assert float((c["scores"][0] - a["scores"][1]).abs().max()) < 2e-5
+    for k, ref in a_sel.items():
+        d = (c[k] - ref).abs().max() / ref.abs().max()
+        assert float(d) < 5e-4, (k, float(d))
+    # ... and with the SAME row mode (token-row map + class-row kernel, what every larger batch takes) it is the same arithmetic in the
+    # same order: image 1 alone == image 1 inside the batch
+    monkeypatch.setenv("MHMR_TINY_ALLROWS", "0")
+    c = model_896(x[1:2], idx=idx1, K=K[1:2], is_training=True)
+    for k, ref in a_sel.items():
+        d = (c[k] - ref).abs().max() / ref.abs().max()
+        assert float(d) < 1e-6, (k, float(d))
+    assert float((c["scores"][0] - a_scores).abs().max()) < 1e-6
 
 
 def test_lbs_160_persons_linear_in_betas_at_zero_pose(smplx_data):
