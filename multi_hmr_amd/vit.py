@@ -307,14 +307,14 @@ class WorkspaceCache:
         nsplit > 1: the batch is cut into nsplit contiguous image blocks with a backbone workspace + descriptor each (``ws["parts"]``:
         dicts with ``desc``, ``B``, ``img0``), so that the blocks can run on different streams (model.Model, MHMR_SPLIT); ``feat32`` and
         the extras cover the whole batch.  The top-level buffer names (``hid`` ...) are those of part 0."""
-        key = (id(P), B, nsplit)
+        if B % nsplit:
+            raise ValueError(f"batch {B} does not split into {nsplit} equal image blocks")
+        key = (id(P), B, nsplit, padded_tokens(P, B // nsplit))       # (the row padding follows environment switches: A/B runs in one process)
         if key in self._ws:
             self._ws[key] = self._ws.pop(key)             # most recent last
             return self._ws[key]
         while len(self._ws) >= self.KEEP:                 # free the oldest before allocating
             self._ws.pop(next(iter(self._ws)))
-        if B % nsplit:
-            raise ValueError(f"batch {B} does not split into {nsplit} equal image blocks")
         dev, tdt = P["device"], P["tdt"]
         Bh = B // nsplit
         Cd, N, Tp, H = P["C"], P["N"], padded_tokens(P, Bh), P["H"]
