@@ -25,6 +25,11 @@ PY
 tail -3 $OUT/bench.err >> $OUT/summary.txt
 echo "== two-stream soak" >> $OUT/summary.txt
 MHMR_SOAK_BATCH=8 MHMR_SPLIT=2 REPS=200 timeout 500 python tools/two_stream_check.py 24 2>&1 | grep -v amdgpu.ids | cut -c1-300 | tail -3 >> $OUT/summary.txt
+echo "== the opt-in paths on this build (MHMR_LO8=1: fp8 low-half ranges; MHMR_LBS_FUSED=1: one-launch SMPL-X layer)" >> $OUT/summary.txt
+MHMR_LO8=1 timeout 300 python -m pytest tests/test_gpu_parity_fullsize.py -q -p no:cacheprovider -k "vitl_672_full-f16 or vitl_896_full-f16" 2>&1 | tail -1 >> $OUT/summary.txt
+MHMR_LBS_FUSED=1 timeout 300 python -m pytest tests/test_gpu_model.py -q -p no:cacheprovider -k "training_mode or inference_mode" 2>&1 | tail -1 >> $OUT/summary.txt
+echo "== bench under torch.distributed.run, RCCL group of one" >> $OUT/summary.txt
+timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-400 >> $OUT/summary.txt
 echo "== x3 cost" >> $OUT/summary.txt
 timeout 300 python tools/x3_bench.py 8 >> $OUT/summary.txt 2>/dev/null
 echo "== profiles" >> $OUT/summary.txt
