@@ -180,3 +180,28 @@ def test_auto_precision_follows_the_weights(smplx_data, mean_params):
     for k in CHECKED:
         assert eh[k] < 3e-4, (k, eh[k])
     assert max(ep.values()) > 4 * max(eh.values())
+
+
+@pytest.mark.parametrize("name", ["vits_448_infer", "vitl_448_infer"])
+def test_x3_inference_mode_person_list_matches_reference_golden(name, smplx_data, mean_params):
+    """The f16x3 backbone in front of the unchanged detection / NMS / heads: the reference's person list (same persons, same order) on the
+    inference goldens (depth-2 ViT-S on the 128x128 kernel; the FULL-depth ViT-L, two images = a tiny batch), every tensor far inside 1e-3."""
+    from oracle import roma_ref
+    cfg = make_golden.CASES[name]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    sd = make_golden.case_state_dict(cfg)
+    sd["mlp_classif.2.bias"] = torch.from_numpy(gold["classif_bias"])
+    model = _build(cfg, smplx_data, mean_params, "f16x3", sd)
+    x, K, _ = make_golden.case_inputs(cfg)
+    humans = model(x.cuda(), K=K.cuda(), is_training=False, det_thresh=float(gold["det_thresh"]), nms_kernel_size=cfg["nms_kernel_size"])
+    assert model.packed_precision == "f16x3" and len(humans) == int(gold["num_humans"])
+    for k in humans[0].keys():
+        got = torch.stack([h[k] for h in humans]).cpu()
+        if k == "v3d":
+            got = got[:, :: cfg.get("vstride", 1)]
+        if k == "rotvec":
+            e = rel(roma_ref.rotvec_to_rotmat(got).numpy(), roma_ref.rotvec_to_rotmat(torch.from_numpy(gold["h_rotvec"])).numpy())
+        else:
+            e = rel(got.numpy(), gold["h_" + k])
+        assert e < 3e-4, (k, e)
+    assert model(x.cuda(), K=K.cuda(), det_thresh=2.0) == []
