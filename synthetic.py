@@ -280,7 +280,7 @@ def make_pinned_idx(batch: int, grid: int, per_image: int, seed: int = 0):
     return (b, y, x, torch.zeros_like(b))
 
 
-def make_hostile(sd: dict, kind: str, seed: int = 0) -> dict:
+def make_hostile(sd: dict, kind: str, seed: int = 0, strength: float = 1.0) -> dict:
     """Weight statistics a TRAINED DINOv2 checkpoint can have and ``make_state_dict`` does not (round-3 review: the precision scheme --
     low-half weight passes, LayerNorm fold -- was tuned on N(1, 0.1) LayerNorm / LayerScale weights).  Applied to the backbone in place:
 
@@ -290,6 +290,9 @@ def make_hostile(sd: dict, kind: str, seed: int = 0) -> dict:
                  and on every proj / fc2 bias, so that |mean| / std of a residual row stays around 2 through the depth -- the case the
                  LayerNorm fold is sensitive to (it rounds the RAW row to 16 bits and centres afterwards)
     """
+    # strength (kind "weights" only): 1 = the statistics above (what the goldens were made with: the same random draws, bit for bit);
+    # < 1 interpolates towards benign weights -- hot channels x(1 + strength (f - 1)), log-normal sigma and biases scaled by strength --
+    # for probing where the `precision="auto"` rule (multi_hmr_amd/vit.py logit_gain) has to switch
     g = torch.Generator().manual_seed(7000 + seed)
     p = "backbone.encoder."
     L = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith(p + "blocks."))
@@ -301,12 +304,12 @@ def make_hostile(sd: dict, kind: str, seed: int = 0) -> dict:
             for n in ("ls1.gamma", "ls2.gamma"):
                 sd[b + n] = torch.exp(torch.empty(C).uniform_(math.log(1e-3), 0.0, generator=g))
             for n in ("norm1", "norm2"):
-                w = torch.exp(0.5 * rn(C))
+                w = torch.exp(0.5 * strength * rn(C))
                 hot = torch.randperm(C, generator=g)[:6]
-                w[hot] *= torch.tensor([10.0, 10.0, 10.0, 10.0, 30.0, 30.0])
+                w[hot] *= 1.0 + strength * (torch.tensor([10.0, 10.0, 10.0, 10.0, 30.0, 30.0]) - 1.0)
                 sd[b + n + ".weight"] = w
-                sd[b + n + ".bias"] = (0.7 * rn(C)).clamp_(-2, 2)
-            sd[b + "attn.qkv.bias"] = rn(3 * C)
+                sd[b + n + ".bias"] = (0.7 * strength * rn(C)).clamp_(-2, 2)
+            sd[b + "attn.qkv.bias"] = strength * rn(3 * C)
     elif kind == "mean":
         sd[p + "patch_embed.proj.bias"] = sd[p + "patch_embed.proj.bias"] + 1.7
         for i in range(L):
