@@ -34,9 +34,14 @@ def load_model(model_name, device=torch.device("cuda"), **model_kwargs):
     return model
 
 
-def forward_model(model, input_image, camera_parameters, det_thresh=0.3, nms_kernel_size=1):
+def forward_model(model, input_image, camera_parameters, det_thresh=0.3, nms_kernel_size=1, use_graph=False):
     """demo.py:108-126.  The reference wraps the call in fp16 autocast; ``Model.forward`` disables autocast for
-    its own body, so the precision is whatever ``Model(precision=...)`` selected."""
+    its own body, so the precision is whatever ``Model(precision=...)`` selected.
+    Extension: ``use_graph=True`` replays the forward from a hipGraph recorded on first use for this batch size / threshold / NMS window
+    (``graphed.GraphedForward``: same kernels, same results; what it saves is the host's per-launch work, which matters at batch 1)."""
+    if use_graph:
+        from .graphed import graphed
+        return graphed(model, input_image.shape[0], det_thresh, nms_kernel_size)(input_image.float(), camera_parameters.float())
     with torch.no_grad():
         with torch.autocast("cuda", enabled=True):
             humans = model(input_image, is_training=False, nms_kernel_size=int(nms_kernel_size), det_thresh=det_thresh,

@@ -479,31 +479,12 @@ class Model(nn.Module):
     def _forward(self, x, idx, det_thresh, nms_kernel_size, K, is_training, with_ids=False, batched=False):
         L = _lib.lib()
         P, ws, stream = self._prepare(x)
-        dev, B, G, N, Cdim, Kc = x.device, x.shape[0], P["G"], P["N"], P["C"], P["Kc"]
-        dt = P["dt_id"]
+        dev, B, G = x.device, x.shape[0], P["G"]
         K = K.to(device=dev, dtype=torch.float32).contiguous()
         assert K.shape == (B, 3, 3)
-        Mp = ws["ctx16"].shape[0]
-        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
 
-        # 1. backbone (model.py:229) -> feat32 + 16-bit context operand
-        self._run_backbone(P, ws, x)
-        # 2. camera embedding (model.py:262) -> zK + context operand columns C..C+98
-        _lib.check(L.mhmr_camera_embed(K.data_ptr(), P["freq"].data_ptr(), B, G, PATCH, ws["zK"].data_ptr(), ws["ctx16"].data_ptr(), Kc,
-                                       Cdim, dt, P["nbands"], stream), "mhmr_camera_embed")
-        # 3. detection scores (model.py:135): mlp_classif.0 + ReLU on MFMA, then the C->1 read-out + clamped sigmoid
-        _lib.check(L.mhmr_gemm16(ws["ctx16"].data_ptr(), Kc, P["cls0_w"].data_ptr(), Cdim, Mp, Cdim, Cdim, P["cls0_b"].data_ptr(), None,
-                                 ws["hid_cls"].data_ptr(), Cdim, None, 0, 128, 1, Mp, _lib.EPI_OP16_RELU, dt, stream), "mhmr_gemm16(classif)")
-        _lib.check(L.mhmr_detect_scores(ws["hid_cls"].data_ptr(), Cdim, P["cls2_w"].data_ptr(), P["cls2_b"].data_ptr(), ws["scores"].data_ptr(),
-                                        B * N, Cdim, dt, stream), "mhmr_detect_scores")
+        self._front(P, ws, x, K, stream)
         scores = ws["scores"].view(B, G, G, 1)
-
-        # 4. the person set.  Its bookkeeping -- per-image counts, write offsets, the ragged query groups of the decoder (rebatch /
-        # pad_to_max semantics, utils/tensor_manip.py:7-45, without the padding) -- is made ON THE DEVICE (mhmr_person_groups): the
-        # training hook needs no host round trip at all, inference reads the person count back AFTER the whole forward is enqueued.
-        def tables(cap):
-            ngc, ncc = min(B, cap), cap // 8 + min(B, cap)
-            return i32(ngc + 1), i32(3 * max(ncc, 1)), i32(4), ngc, ncc
 
         if is_training:
             # the caller's idx (training hook, model.py:150-151); persons sorted by image as torch.where leaves them
@@ -514,7 +495,7 @@ class Model(nn.Module):
             if Pn == 0:
                 return out
             det = torch.stack([idx[0], idx[1], idx[2]]).to(torch.int32).contiguous()
-            gstart_t, chunks_t, info, ngc, ncc = tables(Pn)
+            gstart_t, chunks_t, info, ngc, ncc = self._tables(B, Pn, dev)
             _lib.check(L.mhmr_person_groups(None, det[0].data_ptr(), Pn, B, Pn, None, gstart_t.data_ptr(), ngc, chunks_t.data_ptr(), ncc,
                                             info.data_ptr(), stream), "mhmr_person_groups")
             out.update(self._heads(P, ws, K, det, Pn, gstart_t, ngc, chunks_t, ncc, None, stream))
@@ -523,31 +504,7 @@ class Model(nn.Module):
         # NMS + threshold + ordered compaction (model.py:141-149)
         thr = float(det_thresh[0] if isinstance(det_thresh, list) else det_thresh)
         k = int(nms_kernel_size)
-        _lib.check(L.mhmr_detect_count(ws["scores"].data_ptr(), B, G, k, thr, ws["counts"].data_ptr(), stream), "mhmr_detect_count")
-
-        # per-person dicts (model.py:329-347); v2d / rotmat are computed but not exposed, as in the reference.  One unbind per key
-        # instead of rows x 10 indexing calls (3 ms -> 1 ms of host time at 256 persons).
-        keys = self.PERSON_KEYS
-
-        def person_dicts(o, rows):
-            return [dict(zip(keys, vals)) for vals in zip(*(o[n][:rows].unbind(0) for n in keys))]
-
-        def detect_and_heads(cap, with_dicts):
-            det, scores_det, base = i32(3, cap), torch.zeros(cap, dtype=torch.float32, device=dev), i32(B)
-            gstart_t, chunks_t, info, ngc, ncc = tables(cap)
-            o = self._alloc_outputs(P, cap, dev)
-            o["scores"] = scores_det
-            # The dicts are VIEWS of the output buffers: they are made here, BEFORE the heads are enqueued -- the host is far ahead of the
-            # GPU at this point (the backbone has just been enqueued and runs for >100 ms; its launches are what the later ones queue
-            # behind), so this millisecond of host work is free, whereas after the last launch the GPU has only the ~1 ms tail left
-            # (measured: profiles/r04_session_c_inference_host_cfg5_cfg2.txt).  Dicts of padding rows are dropped unread.
-            persons = person_dicts(o, cap) if with_dicts else None
-            _lib.check(L.mhmr_person_groups(ws["counts"].data_ptr(), None, 0, B, cap, base.data_ptr(), gstart_t.data_ptr(), ngc,
-                                            chunks_t.data_ptr(), ncc, info.data_ptr(), stream), "mhmr_person_groups")
-            _lib.check(L.mhmr_detect_write_cap(ws["scores"].data_ptr(), B, G, k, thr, base.data_ptr(), det[0].data_ptr(), det[1].data_ptr(),
-                                               det[2].data_ptr(), scores_det.data_ptr(), cap, stream), "mhmr_detect_write_cap")
-            self._heads(P, ws, K, det, cap, gstart_t, ngc, chunks_t, ncc, info, stream, o)
-            return o, det, info, persons
+        self._count(ws, B, G, k, thr, stream)
 
         # Fixed capacity: the heads are enqueued for `cap` person rows (a little above the previous batch's count; rows behind the real
         # persons are padding that the kernels compute and nobody reads), and the ONE host synchronisation -- the person count, which the
@@ -556,7 +513,7 @@ class Model(nn.Module):
         cap = self._person_cap.get(B)
         o = persons = None
         if cap is not None:
-            o, det, info, persons = detect_and_heads(cap, not batched)
+            o, det, info, persons = self._detect_and_heads(P, ws, K, k, thr, cap, not batched, stream)
             Pn = int(info[3].item())                       # the host sync
             if Pn > cap:
                 o = persons = None
@@ -568,12 +525,69 @@ class Model(nn.Module):
         if Pn == 0:
             return (([] if not batched else {}), torch.zeros(0, dtype=torch.int32, device=dev)) if (with_ids or batched) else []
         if o is None:
-            o, det, info, persons = detect_and_heads(Pn, not batched)
+            o, det, info, persons = self._detect_and_heads(P, ws, K, k, thr, Pn, not batched, stream)
         ids = det[0][:Pn]
         if batched:
-            return {n: o[n][:Pn] for n in keys}, ids
+            return {n: o[n][:Pn] for n in self.PERSON_KEYS}, ids
         persons = persons[:Pn]
         return (persons, ids) if with_ids else persons
+
+    # ---- the pieces of the inference forward (shared with graphed.GraphedForward, which records them into a hipGraph once)
+    def _front(self, P, ws, x, K, stream):
+        """Steps 1-3 of the forward: backbone, camera embedding, detection scores -> ws["feat32"], ws["ctx16"], ws["zK"], ws["scores"]."""
+        L = _lib.lib()
+        B, G, N, Cdim, Kc, dt = x.shape[0], P["G"], P["N"], P["C"], P["Kc"], P["dt_id"]
+        Mp = ws["ctx16"].shape[0]
+        # 1. backbone (model.py:229) -> feat32 + 16-bit context operand
+        self._run_backbone(P, ws, x)
+        # 2. camera embedding (model.py:262) -> zK + context operand columns C..C+98
+        _lib.check(L.mhmr_camera_embed(K.data_ptr(), P["freq"].data_ptr(), B, G, PATCH, ws["zK"].data_ptr(), ws["ctx16"].data_ptr(), Kc,
+                                       Cdim, dt, P["nbands"], stream), "mhmr_camera_embed")
+        # 3. detection scores (model.py:135): mlp_classif.0 + ReLU on MFMA, then the C->1 read-out + clamped sigmoid
+        _lib.check(L.mhmr_gemm16(ws["ctx16"].data_ptr(), Kc, P["cls0_w"].data_ptr(), Cdim, Mp, Cdim, Cdim, P["cls0_b"].data_ptr(), None,
+                                 ws["hid_cls"].data_ptr(), Cdim, None, 0, 128, 1, Mp, _lib.EPI_OP16_RELU, dt, stream), "mhmr_gemm16(classif)")
+        _lib.check(L.mhmr_detect_scores(ws["hid_cls"].data_ptr(), Cdim, P["cls2_w"].data_ptr(), P["cls2_b"].data_ptr(), ws["scores"].data_ptr(),
+                                        B * N, Cdim, dt, stream), "mhmr_detect_scores")
+
+    def _count(self, ws, B, G, k, thr, stream):
+        """Per-image person counts of the NMS + threshold (model.py:141-146) -> ws["counts"]."""
+        _lib.check(_lib.lib().mhmr_detect_count(ws["scores"].data_ptr(), B, G, k, thr, ws["counts"].data_ptr(), stream), "mhmr_detect_count")
+
+    @staticmethod
+    def _tables(B, cap, dev):
+        """The person set's bookkeeping tables -- per-image write offsets, the ragged query groups of the decoder (rebatch / pad_to_max
+        semantics, utils/tensor_manip.py:7-45, without the padding) -- are filled ON THE DEVICE (mhmr_person_groups): the training hook
+        needs no host round trip at all, inference reads the person count back AFTER the whole forward is enqueued."""
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
+        ngc, ncc = min(B, cap), cap // 8 + min(B, cap)
+        return i32(ngc + 1), i32(3 * max(ncc, 1)), i32(4), ngc, ncc
+
+    def _person_dicts(self, o, rows):
+        """Per-person dicts (model.py:329-347); v2d / rotmat are computed but not exposed, as in the reference.  One unbind per key
+        instead of rows x 10 indexing calls (3 ms -> 1 ms of host time at 256 persons)."""
+        keys = self.PERSON_KEYS
+        return [dict(zip(keys, vals)) for vals in zip(*(o[n][:rows].unbind(0) for n in keys))]
+
+    def _detect_and_heads(self, P, ws, K, k, thr, cap, with_dicts, stream):
+        """Ordered compaction of the detections into `cap` person rows + HPH + SMPL-X layer for those rows (ws["counts"] is in flight)."""
+        L = _lib.lib()
+        dev, B, G = K.device, K.shape[0], P["G"]
+        det = torch.zeros(3, cap, dtype=torch.int32, device=dev)
+        scores_det, base = torch.zeros(cap, dtype=torch.float32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+        gstart_t, chunks_t, info, ngc, ncc = self._tables(B, cap, dev)
+        o = self._alloc_outputs(P, cap, dev)
+        o["scores"] = scores_det
+        # The dicts are VIEWS of the output buffers: they are made here, BEFORE the heads are enqueued -- the host is far ahead of the
+        # GPU at this point (the backbone has just been enqueued and runs for >100 ms; its launches are what the later ones queue
+        # behind), so this millisecond of host work is free, whereas after the last launch the GPU has only the ~1 ms tail left
+        # (measured: profiles/r04_session_c_inference_host_cfg5_cfg2.txt).  Dicts of padding rows are dropped unread.
+        persons = self._person_dicts(o, cap) if with_dicts else None
+        _lib.check(L.mhmr_person_groups(ws["counts"].data_ptr(), None, 0, B, cap, base.data_ptr(), gstart_t.data_ptr(), ngc,
+                                        chunks_t.data_ptr(), ncc, info.data_ptr(), stream), "mhmr_person_groups")
+        _lib.check(L.mhmr_detect_write_cap(ws["scores"].data_ptr(), B, G, k, thr, base.data_ptr(), det[0].data_ptr(), det[1].data_ptr(),
+                                           det[2].data_ptr(), scores_det.data_ptr(), cap, stream), "mhmr_detect_write_cap")
+        self._heads(P, ws, K, det, cap, gstart_t, ngc, chunks_t, ncc, info, stream, o)
+        return o, det, info, persons
 
     def _alloc_outputs(self, P, Pn, dev):
         """The output tensors of the heads for Pn person rows (views of them are what forward returns)."""
