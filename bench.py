@@ -436,6 +436,14 @@ def latency_b1(dtype, smplx_data, mean_params, dev, reps=30, persons=4):
             same = len(hg) == len(humans) and all(torch.equal(p[k], q[k]) for p, q in zip(hg, humans) for k in p)
             graph = {"graph_ms": round(1e3 * sorted(wg)[len(wg) // 2], 3), "graph_gpu_ms": round(sorted(gg)[len(gg) // 2], 3),
                      "graph_min_ms": round(1e3 * min(wg), 3), "graph_equals_eager": bool(same)}
+            # the replay alone (no copy into the graph's input, no clones of its outputs) at the eager call's own person capacity
+            from multi_hmr_amd.graphed import GraphedForward
+            gf = GraphedForward(model, 1, thr, 3, capacity=model._person_cap.get(1, 16))
+            gf.x.copy_(x)
+            gf.K.copy_(K)
+            _, wr, _ = clock(gf.replay)
+            graph["graph_replay_ms"] = round(1e3 * sorted(wr)[len(wr) // 2], 3)
+            del gf
         except Exception as e:                                          # noqa: BLE001
             graph = {"graph_ms": None, "graph_error": f"{type(e).__name__}: {e}"[:200]}
         cfg = synthetic.VIT_CFG[backbone]

@@ -15,7 +15,7 @@ is exactly what makes it recordable: the graph holds backbone -> camera embeddin
 * A batch that detects MORE persons than ``capacity`` is re-run through the eager path at its exact size (``overflows`` counts them) --
   the HIP path either way; nothing here computes on the CPU.
 * The graph reads ``gf.x`` / ``gf.K`` and writes its own output buffers: ``__call__`` copies the caller's tensors in (device to device) and
-  returns CLONES of the person rows unless ``copy=False`` (views, valid until the next call).  A producer that writes the preprocessed image
+  returns views of ONE copy of its output block unless ``copy=False`` (views of the block itself, valid until the next call).  A producer that writes the preprocessed image
   straight into ``gf.x`` (``preprocess.py``) saves the copy: ``gf.replay()``.
 * One instance = one (model, device, batch, threshold, NMS window, capacity); the model's weights are read through the packed copies the
   model holds, so ``load_state_dict`` / a device move after recording needs a new instance (checked: the pack's identity).
@@ -87,7 +87,9 @@ class GraphedForward:
                 return self.model(x, K=K, det_thresh=self.det_thresh, nms_kernel_size=self.nms_kernel_size, return_batched=return_batched)
             if Pn == 0:
                 return ({}, torch.zeros(0, dtype=torch.int32, device=self.x.device)) if return_batched else []
-            o = {n: (self.out[n][:Pn].clone() if copy else self.out[n][:Pn]) for n in keys}
+            # copy: ONE device copy of the output block (all capacity rows), the person rows are views of that copy
+            src = self.model._alloc_outputs(self._pack, self.capacity, self.x.device, flat=self.out["_flat"].clone()) if copy else self.out
+            o = {n: src[n][:Pn] for n in keys}
             if return_batched:
                 ids = self.det[0][:Pn]
                 return o, (ids.clone() if copy else ids)

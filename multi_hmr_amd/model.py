@@ -498,7 +498,8 @@ class Model(nn.Module):
             gstart_t, chunks_t, info, ngc, ncc = self._tables(B, Pn, dev)
             _lib.check(L.mhmr_person_groups(None, det[0].data_ptr(), Pn, B, Pn, None, gstart_t.data_ptr(), ngc, chunks_t.data_ptr(), ncc,
                                             info.data_ptr(), stream), "mhmr_person_groups")
-            out.update(self._heads(P, ws, K, det, Pn, gstart_t, ngc, chunks_t, ncc, None, stream))
+            heads = self._heads(P, ws, K, det, Pn, gstart_t, ngc, chunks_t, ncc, None, stream)
+            out.update({n: t for n, t in heads.items() if n not in ("scores", "_flat")})      # (scores here = the [B, G, G, 1] map, model.py:349)
             return out
 
         # NMS + threshold + ordered compaction (model.py:141-149)
@@ -573,10 +574,10 @@ class Model(nn.Module):
         L = _lib.lib()
         dev, B, G = K.device, K.shape[0], P["G"]
         det = torch.zeros(3, cap, dtype=torch.int32, device=dev)
-        scores_det, base = torch.zeros(cap, dtype=torch.float32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+        base = torch.zeros(B, dtype=torch.int32, device=dev)
         gstart_t, chunks_t, info, ngc, ncc = self._tables(B, cap, dev)
         o = self._alloc_outputs(P, cap, dev)
-        o["scores"] = scores_det
+        scores_det = o["scores"].zero_()
         # The dicts are VIEWS of the output buffers: they are made here, BEFORE the heads are enqueued -- the host is far ahead of the
         # GPU at this point (the backbone has just been enqueued and runs for >100 ms; its launches are what the later ones queue
         # behind), so this millisecond of host work is free, whereas after the last launch the GPU has only the ~1 ms tail left
@@ -589,14 +590,30 @@ class Model(nn.Module):
         self._heads(P, ws, K, det, cap, gstart_t, ngc, chunks_t, ncc, info, stream, o)
         return o, det, info, persons
 
-    def _alloc_outputs(self, P, Pn, dev):
-        """The output tensors of the heads for Pn person rows (views of them are what forward returns)."""
-        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    #: output tensors of the heads: name -> trailing shape (rows = persons)
+    OUTPUT_SHAPES = (("offset", (2,)), ("loc", (2,)), ("rotmat", (53, 3, 3)), ("rotvec", (53, 3)), ("shape", None), ("expression", (10,)),
+                     ("dist_postprocessed", (1,)), ("dist", (1,)), ("v3d", None), ("v2d", None), ("j3d", (127, 3)), ("j2d", (127, 2)),
+                     ("transl", (3,)), ("scores", ()))
+
+    def _alloc_outputs(self, P, Pn, dev, flat=None):
+        """The output tensors of the heads for Pn person rows (views of them are what forward returns), carved out of ONE allocation
+        (``o["_flat"]``, every tensor 256-byte aligned): one allocator call per forward instead of fourteen, and a consumer that has to
+        keep the results past the next forward of a recorded graph copies one buffer (graphed.GraphedForward).  ``flat``: build the views
+        on an existing buffer of the same layout (such a copy)."""
         nb, V = P["hph"]["nb"], P["lbs"]["V"]
-        o = {"offset": f(Pn, 2), "loc": f(Pn, 2), "rotmat": f(Pn, 53, 3, 3), "rotvec": f(Pn, 53, 3), "shape": f(Pn, nb), "expression": f(Pn, 10),
-             "dist_postprocessed": f(Pn, 1), "dist": f(Pn, 1), "v3d": f(Pn, V, 3), "v2d": f(Pn, V, 2), "j3d": f(Pn, 127, 3), "j2d": f(Pn, 127, 2),
-             "transl": f(Pn, 3)}
+        var = {"shape": (nb,), "v3d": (V, 3), "v2d": (V, 2)}
+        off, lay = 0, []
+        for name, shp in self.OUTPUT_SHAPES:
+            shp = var[name] if shp is None else shp
+            n = Pn * int(np.prod(shp, dtype=np.int64))
+            lay.append((name, shp, off, n))
+            off += -(-n // 64) * 64
+        if flat is None:
+            flat = torch.empty(off, dtype=torch.float32, device=dev)
+        assert flat.numel() == off
+        o = {name: flat[a:a + n].view(Pn, *shp) for name, shp, a, n in lay}
         o["transl_pelvis"] = o["j3d"][:, 0:1]             # [Pn, 1, 3] view of joint 0 (the reference: j3d[:, [0]])
+        o["_flat"] = flat
         return o
 
     def _heads(self, P, ws, K, det, Pn, gstart_t, ngc, chunks_t, ncc, info, stream, o=None):

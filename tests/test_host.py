@@ -369,3 +369,34 @@ def test_three_product_operands_reconstruct_the_fp32_product():
     assert vit.padded_tokens(P, 3) == 384 and not vit.row_map(P, 4)                         # T = 257 -> whole 128-row tiles (C = 384)
     shapes = sorted(tuple(t.shape) for t in P["keep"] if t.dtype == torch.float16)
     assert (384, 3 * 640) in shapes and (3 * 384, 3 * 384) in shapes and (384, 12 * 384) in shapes and (4 * 384, 3 * 384) in shapes
+
+
+def test_output_block_layout_and_the_graph_wrapper_without_a_gpu(smplx_data, mean_params):
+    """Model._alloc_outputs carves every head output out of one allocation (256-byte aligned, contiguous views, rebuildable on a copy of
+    the block: what graphed.GraphedForward hands out); GraphedForward itself refuses to exist without the GPU (no CPU path)."""
+    from multi_hmr_amd import GraphedForward
+    m = Model(backbone="dinov2_vits14", img_size=224, smplx_data=smplx_data, mean_params=mean_params, backbone_depth=1)
+    P = {"hph": {"nb": 10}, "lbs": {"V": 10475}}
+    cpu = torch.device("cpu")
+    o = m._alloc_outputs(P, 5, cpu)
+    flat = o["_flat"]
+    names = [n for n, _ in Model.OUTPUT_SHAPES]
+    assert set(o) == set(names) | {"transl_pelvis", "_flat"} and set(Model.PERSON_KEYS) <= set(o)
+    assert o["v3d"].shape == (5, 10475, 3) and o["rotmat"].shape == (5, 53, 3, 3) and o["scores"].shape == (5,) and o["shape"].shape == (5, 10)
+    spans = []
+    for n in names:
+        t = o[n]
+        assert t.is_contiguous() and (t.data_ptr() - flat.data_ptr()) % 256 == 0, n
+        spans.append((t.data_ptr() - flat.data_ptr(), t.numel() * 4))
+    spans.sort()
+    assert all(a + la <= b for (a, la), (b, _) in zip(spans, spans[1:])) and spans[-1][0] + spans[-1][1] <= flat.numel() * 4     # disjoint, inside
+    assert o["transl_pelvis"].shape == (5, 1, 3) and o["transl_pelvis"].data_ptr() == o["j3d"].data_ptr()
+    for i, n in enumerate(names):
+        o[n].fill_(float(i))
+    o2 = m._alloc_outputs(P, 5, cpu, flat=flat.clone())
+    assert all(torch.equal(o2[n], o[n]) and o2[n].data_ptr() != o[n].data_ptr() for n in names)
+    with pytest.raises(AssertionError):
+        m._alloc_outputs(P, 6, cpu, flat=flat)           # a block of another capacity
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.MhmrError):
+            GraphedForward(m, batch=1)
