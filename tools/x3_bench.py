@@ -41,5 +41,8 @@ def run(B, S, backbone, hostile, precision, steps=5):
 
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-    out = [run(B, 672, "dinov2_vitl14", True, "auto"), run(B, 672, "dinov2_vitl14", False, "auto"), run(B, 672, "dinov2_vitl14", True, "f16")]
+    if len(sys.argv) > 2 and sys.argv[2] == "x3only":          # kernel traces: the f16x3 forward alone
+        out = [run(B, 672, "dinov2_vitl14", True, "auto")]
+    else:
+        out = [run(B, 672, "dinov2_vitl14", True, "auto"), run(B, 672, "dinov2_vitl14", False, "auto"), run(B, 672, "dinov2_vitl14", True, "f16")]
     print(json.dumps(out))
