@@ -555,13 +555,21 @@ class Model(nn.Module):
         _lib.check(_lib.lib().mhmr_detect_count(ws["scores"].data_ptr(), B, G, k, thr, ws["counts"].data_ptr(), stream), "mhmr_detect_count")
 
     @staticmethod
-    def _tables(B, cap, dev):
+    def _tables(B, cap, dev, with_det=False):
         """The person set's bookkeeping tables -- per-image write offsets, the ragged query groups of the decoder (rebatch / pad_to_max
         semantics, utils/tensor_manip.py:7-45, without the padding) -- are filled ON THE DEVICE (mhmr_person_groups): the training hook
-        needs no host round trip at all, inference reads the person count back AFTER the whole forward is enqueued."""
-        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
+        needs no host round trip at all, inference reads the person count back AFTER the whole forward is enqueued.
+        One zeroed int32 block (one fill launch, not one per table) -> gstart [ngc + 1], chunks [3 ncc], info [4], ngc, ncc and, with
+        ``with_det``, the detection triple det [3, cap] and the per-image write offsets base [B] of the inference path."""
         ngc, ncc = min(B, cap), cap // 8 + min(B, cap)
-        return i32(ngc + 1), i32(3 * max(ncc, 1)), i32(4), ngc, ncc
+        sizes = [ngc + 1, 3 * max(ncc, 1), 4] + ([3 * cap, B] if with_det else [])
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + -(-n // 16) * 16)              # 64-byte aligned pieces
+        blk = torch.zeros(offs[-1], dtype=torch.int32, device=dev)
+        pieces = [blk[a:a + n] for a, n in zip(offs, sizes)]
+        out = (pieces[0], pieces[1], pieces[2], ngc, ncc)
+        return out + (pieces[3].view(3, cap), pieces[4]) if with_det else out
 
     def _person_dicts(self, o, rows):
         """Per-person dicts (model.py:329-347); v2d / rotmat are computed but not exposed, as in the reference.  One unbind per key
@@ -573,9 +581,7 @@ class Model(nn.Module):
         """Ordered compaction of the detections into `cap` person rows + HPH + SMPL-X layer for those rows (ws["counts"] is in flight)."""
         L = _lib.lib()
         dev, B, G = K.device, K.shape[0], P["G"]
-        det = torch.zeros(3, cap, dtype=torch.int32, device=dev)
-        base = torch.zeros(B, dtype=torch.int32, device=dev)
-        gstart_t, chunks_t, info, ngc, ncc = self._tables(B, cap, dev)
+        gstart_t, chunks_t, info, ngc, ncc, det, base = self._tables(B, cap, dev, with_det=True)
         o = self._alloc_outputs(P, cap, dev)
         scores_det = o["scores"].zero_()
         # The dicts are VIEWS of the output buffers: they are made here, BEFORE the heads are enqueued -- the host is far ahead of the
