@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define MHMR_VERSION 104   /* 104: mhmr_vit_desc.{x3, qkv32, hid32}: the f16x3 precision mode (three 16-bit products per term in every backbone linear, fp32 attention); mhmr_gemm16_ex a_k with K = 3 a_k; mhmr_attention_f32; 103: mhmr_attention16_ex variant 6 (the default of mhmr_vit_forward); mhmr_camera_embed(num_bands), mhmr_hph_desc.cam_dim; mhmr_lbs_consts.basis16 layout (high halves for k < Kb - 64); mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
+#define MHMR_VERSION 105   /* 105: mhmr_vit_desc.{splitk, splitk_bytes}, mhmr_splitk_workspace_bytes, mhmr_gemm16_splitk_resid: split-k residual linears for launches that fill less than half the chip (a batch of one); 104: mhmr_vit_desc.{x3, qkv32, hid32}: the f16x3 precision mode (three 16-bit products per term in every backbone linear, fp32 attention); mhmr_gemm16_ex a_k with K = 3 a_k; mhmr_attention_f32; 103: mhmr_attention16_ex variant 6 (the default of mhmr_vit_forward); mhmr_camera_embed(num_bands), mhmr_hph_desc.cam_dim; mhmr_lbs_consts.basis16 layout (high halves for k < Kb - 64); mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
 
 #define MHMR_OK 0
 #define MHMR_ERR_BAD_ARG (-1)
@@ -127,6 +127,14 @@ typedef struct {
     int x3;
     float* qkv32;           /* x3: [B*Tp, 3C] fp32  (Q | K | V), bias included                                                 */
     float* hid32;           /* x3: [B*Tp, 4C] fp32  fc1 output before the GELU                                                 */
+    /* Split-k workspace, or NULL.  When every row goes through the 256x256 kernel (Tp % 256 == 0 with N % 256 == 0: the "all rows" form a
+     * caller picks for tiny batches) and a residual linear (proj / fc2) has at most half as many 256x256 tiles as the device has CUs, its k
+     * range is cut into slices whose fp32 partial tiles go here -- mhmr_splitk_workspace_bytes(B*Tp, C, 4C) bytes cover every linear -- and
+     * a row-wise kernel sums them in slice order, applies bias / LayerScale / residual and leaves xn and rowstats (no ln_stats launch).
+     * Deterministic; the summation order differs from the unsplit linear's, i.e. from the same image inside a large batch, at the 16-bit
+     * noise level -- as the all-rows form itself already does. */
+    float* splitk;
+    long long splitk_bytes;
 } mhmr_vit_desc;
 
 /* x: [B,3,S,S] fp32 (ImageNet-normalised).  feat32: [B*N, C] fp32 patch features (token n = y*G + x).
@@ -152,6 +160,15 @@ int mhmr_gemm16_ex(const void* A, int lda, const void* W, int ldw, int M, int N,
 int mhmr_gemm16_ln(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias,
                    const float* gamma, void* out, int ldo, int Tp, int H, int epi, int dtype, int img_rows, int img_stride,
                    int a_k, void* x16, float* pstats, const float* rowstats, const float* colsum, const float* fbias, void* stream);
+/* Split-k residual linear (csrc/gemm256.hip SPLITK + csrc/vit_misc.hip splitk_resid_kernel): out32 += gamma * (A . W^T + bias) for a launch
+ * that would otherwise occupy at most half of the CUs.  mhmr_splitk_workspace_bytes: bytes of fp32 partial tiles the pair needs for an
+ * [M, N] output over K (0 = such a problem is not split: M, N % 256, K % 128, tiles <= CUs / 2, K >= 512).  a_k as in mhmr_gemm16_ex.
+ * x16 (row pitch ldx16 elements, 0 = N) receives the op16 copy of the updated rows and rowstats [M, 2] their (mean, rstd) with the centred
+ * variance (eps inside the square root); either may be NULL.  N must be 256, 512, 768 or 1024 (one wave per row in the reduction). */
+long long mhmr_splitk_workspace_bytes(int M, int N, int K);
+int mhmr_gemm16_splitk_resid(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int a_k, const float* bias,
+                             const float* gamma, float* out32, void* x16, int ldx16, float* rowstats, float eps, float* ws,
+                             long long ws_bytes, int dtype, void* stream);
 /* rowstats[b*Tp + n] = (mean, rstd) of residual row (b, n): n < N from the block sums pstats[b*Tp + n][C/64][2], n == N (the class row)
  * from the fp32 row resid[b*Tp + N][C] itself.                                                                                       */
 /* mhmr_gemm16_ln with an fp8 low-half range (csrc/gemm256.hip, GemmArgs::lo8; epi = MHMR_EPI_VT or MHMR_EPI_RESID only): A rows = [a_k op16 |

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(CSRC, "libmhmr.so")
 SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "attention_f32.hip", "vit_misc.hip", "vit_cls.hip", "hph.hip", "lbs.hip", "preprocess.hip", "evalm.hip", "anny.hip", "capi.hip"]
 HEADERS = ["mhmr_common.h", "mhmr_internal.h", os.path.join("..", "..", "include", "mhmr.h")]
 
-VERSION = 104                       # include/mhmr.h MHMR_VERSION (struct layouts and entry-point semantics)
+VERSION = 105                       # include/mhmr.h MHMR_VERSION (struct layouts and entry-point semantics)
 DT_BF16, DT_F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 EPI_OP16, EPI_OP16_GELU, EPI_OP16_RELU, EPI_RESID, EPI_PATCH, EPI_F32, EPI_VT, EPI_OP16_QK = range(8)
@@ -106,7 +106,7 @@ class VitDesc(C.Structure):
                 [("patch_w", _vp), ("patch_b", _vp), ("cls_pos0", _vp), ("pos", _vp), ("blocks", C.POINTER(VitBlock)),
                  ("norm_w", _vp), ("norm_b", _vp)] +
                 [(n, _vp) for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid", "attn_flags", "pstats", "rowstats")] +
-                [("lo8", _i), ("x3", _i), ("qkv32", _vp), ("hid32", _vp)])
+                [("lo8", _i), ("x3", _i), ("qkv32", _vp), ("hid32", _vp), ("splitk", _vp), ("splitk_bytes", C.c_longlong)])
 
 
 class HphLayer(C.Structure):
@@ -136,6 +136,8 @@ _SIGS = {
     "mhmr_gemm16_ex": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mhmr_gemm16_ln": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "mhmr_gemm16_lo8": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
+    "mhmr_splitk_workspace_bytes": ([_i, _i, _i], C.c_longlong),
+    "mhmr_gemm16_splitk_resid": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, C.c_longlong, _i, _vp], _i),
     "mhmr_ln_stats": ([_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
     "mhmr_cls_linear16": ([_vp, C.c_longlong, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, C.c_longlong, _i, _i, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "mhmr_attention16": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),

@@ -39,7 +39,21 @@ int mhmr_launch_attention_f32(const float* qkv, void* out, int B, int T, int Tp,
 int mhmr_launch_im2col_pair(const float* x, void* a, int B, int S, int G, int Kp, int dtype, hipStream_t s);
 int mhmr_launch_layernorm_pair(const float* in, const float* w, const float* b, void* out16, int rows, int C, float eps, int dtype, hipStream_t s);
 int mhmr_launch_gelu_pair(const float* in, void* out, long long M, int N, int dtype, hipStream_t s);
+int mhmr_launch_splitk_resid(const float* part, int nslices, int rows, int C, const float* bias, const float* gamma, float* resid, void* x16,
+                             int ldx, float* rowstats, float eps, int dtype, hipStream_t s);
+bool mhmr_splitk_plan(int M, int N, int K, int* ksplit, int* nslices);
 int mhmr_launch_loc(const float* offset, const int* det_y, const int* det_x, int patch, float* loc, int P, hipStream_t s);
+
+thread_local int g_mhmr_anyorder = 0;        // mhmr_internal.h: the next launches of this host thread go out without the AQL barrier bit
+#ifndef MHMR_ANYORDER_DEFAULT
+#define MHMR_ANYORDER_DEFAULT 0
+#endif
+namespace {
+struct AnyOrder {       // scope guard
+    explicit AnyOrder(bool on) { g_mhmr_anyorder = on ? 1 : 0; }
+    ~AnyOrder() { g_mhmr_anyorder = 0; }
+};
+}  // namespace
 
 // ------------------------------------------------------------------------------------------------ profiler
 namespace {
@@ -166,6 +180,29 @@ int mhmr_gemm16_lo8(const void* A, int lda, const void* W, int ldw, int M, int N
     g.colsum = colsum;
     g.fbias = fbias;
     return mhmr_launch_gemm(g, dtype, (hipStream_t)stream);
+}
+
+long long mhmr_splitk_workspace_bytes(int M, int N, int K) {
+    int ks = 0, S = 0;
+    return mhmr_splitk_plan(M, N, K, &ks, &S) ? (long long)S * M * N * 4 : 0;
+}
+
+// out32 += gamma * (A . W^T + bias) as a split-k linear (a SHORT launch: mhmr_splitk_workspace_bytes(M, N, K) > 0) + the reduction that also
+// leaves x16 / rowstats (either may be NULL)
+int mhmr_gemm16_splitk_resid(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int a_k, const float* bias, const float* gamma,
+                             float* out32, void* x16, int ldx16, float* rowstats, float eps, float* ws, long long ws_bytes, int dtype,
+                             void* stream) {
+    int ks = 0, S = 0;
+    if (!A || !W || !out32 || !ws) return MHMR_ERR_BAD_ARG;
+    if (!mhmr_splitk_plan(M, N, K, &ks, &S)) return MHMR_ERR_BAD_SHAPE;
+    if ((long long)S * M * N * 4 > ws_bytes) return MHMR_ERR_BAD_ARG;
+    GemmArgs g{A, lda, W, ldw, M, N, K, nullptr, nullptr, ws, N, nullptr, 0, 128, 1, M, EPI_F32};
+    g.a_k = a_k;
+    g.ksplit = ks;
+    g.nslices = S;
+    int rc = mhmr_launch_gemm(g, dtype, (hipStream_t)stream);
+    if (rc) return rc;
+    return mhmr_launch_splitk_resid(ws, S, M, N, bias, gamma, out32, x16, ldx16 > 0 ? ldx16 : N, rowstats, eps, dtype, (hipStream_t)stream);
 }
 
 int mhmr_attention16_pitch(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, int* flags, int ldo,
@@ -319,6 +356,35 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
     // does this block's V / output projection run its low half as an fp8 range?  (needs the 256x256 kernel for that launch; MHMR_LO8=0: A/B)
     auto v8 = [&](const mhmr_vit_block& k) { return lo8 && lo8_env && k.v_w8 && (rowmap || allrows256); };
     auto p8 = [&](const mhmr_vit_block& k) { return lo8 && lo8_env && k.proj_w8 && (rowmap || allrows256); };
+    // Split-k residual linears (a batch of one: all rows through the 256x256 kernel, 68 / 40 tiles on 256 CUs): the k range is cut so that
+    // tiles x slices fill the chip, and the reduction that follows (vit_misc.hip splitk_resid_kernel) runs the residual epilogue AND leaves
+    // the row statistics, so the ln_stats launch behind such a linear disappears.  Needs the workspace mhmr_vit_desc.splitk.
+    // Any-order launches (mhmr_internal.h): the V projection and the class-row linears are independent of the big GEMM launched right in
+    // front of them and nothing reads their outputs before the next ordinary launch; not while the stream is being captured, not inside
+    // a profiling window (the hipEvent brackets are ordinary packets)
+    static const bool ao_env = getenv("MHMR_ANYORDER") ? atoi(getenv("MHMR_ANYORDER")) != 0 : MHMR_ANYORDER_DEFAULT != 0;
+    bool ao = ao_env && g_prof.kind < 0;
+    if (ao) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) ao = false;
+    }
+    bool stats_fresh = false;            // rowstats already hold the statistics of the current residual rows
+    auto resid_linear = [&](GemmArgs& g) -> int {
+        int ks = 0, S = 0;
+        stats_fresh = false;
+        if (allrows256 && fold && d->splitk && !g.lo8 && g.x16 && g.ldx16 == 0 && mhmr_splitk_plan(g.M, g.N, g.K, &ks, &S) &&
+            (long long)S * g.M * g.N * 4 <= d->splitk_bytes) {
+            GemmArgs gs{g.A, g.lda, g.W, g.ldw, g.M, g.N, g.K, nullptr, nullptr, d->splitk, g.N, nullptr, 0, Tp, d->H, g.M, EPI_F32};
+            gs.a_k = g.a_k;
+            gs.ksplit = ks;
+            gs.nslices = S;
+            TRY(mhmr_launch_gemm(gs, dt, s));
+            TRY(mhmr_launch_splitk_resid(d->splitk, S, g.M, g.N, g.bias, g.gamma, (float*)g.out, g.x16, g.N, d->rowstats, 1e-6f, dt, s));
+            stats_fresh = true;
+            return 0;
+        }
+        return mhmr_launch_gemm(g, dt, s);
+    };
     for (int l = 0; l < d->L; ++l) {
         const mhmr_vit_block& k = d->blocks[l];
         if (!fold && k.flags) return MHMR_ERR_BAD_ARG;               // folded weights cannot run through the plain LayerNorm path
@@ -340,7 +406,7 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
         const void* p_wc = k.proj_w2 ? k.proj_w2 : k.proj_w;
         const int p_kc = k.proj_w2 ? 2 * C : C, p_akc = k.proj_w2 ? C : 0;
         // x = x + ls1 * proj(MHSA(norm1(x)))
-        if (f1) TRY(ln_stats());
+        if (f1) { if (!stats_fresh) TRY(ln_stats()); }
         else TRY(mhmr_launch_layernorm_pitch(d->resid, k.ln1_w, k.ln1_b, d->xn, pit, vlo8 ? o8 : 0, M, C, 1e-6f, dt, s));
         {
             GemmArgs g{d->xn, pit, k.qkv_w, C, Mg, 2 * C, C, k.qkv_b, nullptr, d->qk, 2 * C, nullptr, 0, Tp, d->H, Mg, EPI_OP16_QK};
@@ -353,6 +419,7 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
                 gv.bias = nullptr; gv.rowstats = d->rowstats; gv.colsum = k.qkv_colsum + 2 * C; gv.fbias = k.qkv_b + 2 * C;
             }
             TRY(mhmr_launch_gemm(g, dt, s));
+            AnyOrder ao_scope(ao);           // V and the class rows of Q | K | V: beside the Q | K projection
             TRY(mhmr_launch_gemm(gv, dt, s));
             if (rowmap) {
                 const char* xr = (const char*)d->xn + (size_t)cls_row * pit * esz;
@@ -375,24 +442,27 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
             if (plo8) { g.lo8 = 1; g.w8_scale = k.proj_w8_scale; }
             rows(g);
             if (fold) { g.x16 = d->xn; g.pstats = d->pstats; g.ldx16 = lo8 ? pit : 0; }
-            TRY(mhmr_launch_gemm(g, dt, s));
+            TRY(resid_linear(g));
+            AnyOrder ao_scope(ao);
             if (rowmap)
                 TRY(mhmr_launch_cls_linear_fold((const char*)d->att + (size_t)cls_row * pit * esz, rowP, p_wc, p_kc, B, C, p_kc, p_akc, k.proj_b, k.ls1,
                                                 d->resid + (size_t)cls_row * C, rowC, 0, C, nullptr, d->H, Tp, 0, 1, dt, nullptr, 0, nullptr, nullptr,
                                                 fold ? (char*)d->xn + (size_t)cls_row * pit * esz : nullptr, rowP, s));
         }
         // x = x + ls2 * fc2(gelu(fc1(norm2(x))))
-        if (f2) TRY(ln_stats());
+        if (f2) { if (!stats_fresh) TRY(ln_stats()); }
         else TRY(mhmr_launch_layernorm_pitch(d->resid, k.ln2_w, k.ln2_b, d->xn, pit, 0, M, C, 1e-6f, dt, s));
         {
             GemmArgs g{d->xn, pit, k.fc1_w, C, Mg, 4 * C, C, k.fc1_b, nullptr, d->hid, 4 * C, nullptr, 0, Tp, d->H, Mg, EPI_OP16_GELU};
             rows(g);
             if (f2) { g.bias = nullptr; g.rowstats = d->rowstats; g.colsum = k.fc1_colsum; g.fbias = k.fc1_b; }
             TRY(mhmr_launch_gemm(g, dt, s));
-            if (rowmap)
+            if (rowmap) {
+                AnyOrder ao_scope(ao);
                 TRY(mhmr_launch_cls_linear_fold((const char*)d->xn + (size_t)cls_row * pit * esz, rowP, k.fc1_w, C, B, 4 * C, C, 0, f2 ? nullptr : k.fc1_b,
                                                 nullptr, (char*)d->hid + (size_t)cls_row * 4 * C * esz, 4 * rowC, 0, C, nullptr, d->H, Tp, 0, 2, dt,
                                                 f2 ? cls_stats : nullptr, 2LL * Tp, k.fc1_colsum, k.fc1_b, nullptr, 0, s));
+            }
             GemmArgs g2{d->hid, 4 * C, k.fc2_w, 4 * C, Mg, C, 4 * C, k.fc2_b, k.ls2, d->resid, C, nullptr, 0, Tp, d->H, Mg, EPI_RESID};
             rows(g2);
             if (fold) {
@@ -400,7 +470,8 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
                 g2.x16 = d->xn; g2.pstats = d->pstats; g2.ldx16 = lo8 ? pit : 0;
                 g2.x8_off = (l + 1 < d->L && v8(d->blocks[l + 1])) ? o8 : 0;
             }
-            TRY(mhmr_launch_gemm(g2, dt, s));
+            TRY(resid_linear(g2));
+            AnyOrder ao_scope2(ao);
             if (rowmap)
                 TRY(mhmr_launch_cls_linear_fold((const char*)d->hid + (size_t)cls_row * 4 * C * esz, 4 * rowC, k.fc2_w, 4 * C, B, C, 4 * C, 0, k.fc2_b,
                                                 k.ls2, d->resid + (size_t)cls_row * C, rowC, 0, C, nullptr, d->H, Tp, 0, 1, dt, nullptr, 0, nullptr,

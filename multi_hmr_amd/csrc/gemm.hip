@@ -282,6 +282,28 @@ struct ColGroupEnv {
 // MHMR_GEMM128=1 forces the 128x128 kernel everywhere (A/B measurements, bisecting)
 static const bool g_force_gemm128 = getenv("MHMR_GEMM128") != nullptr;
 
+// Split-k for a SHORT launch (gemm256.hip SPLITK): when the tiles of an [M, N] output fill at most half of the chip, cut K into nslices
+// slices of ksplit k tiles (whole pairs; the last slice may be shorter) so that tiles x slices fill one round of CUs.  false = do not split.
+// MHMR_SPLITK=0 switches it off (A/B measurements).
+bool mhmr_splitk_plan(int M, int N, int K, int* ksplit, int* nslices) {
+    static const bool on = !(getenv("MHMR_SPLITK") && atoi(getenv("MHMR_SPLITK")) == 0);
+    if (!on || g_force_gemm128 || M <= 0 || M % 256 || N % 256 || K % 128) return false;
+    const int ncu = mhmr_cu_count();
+    const int tiles = (M / 256) * (N / 256), nt = K / 64;
+    if (ncu <= 0 || tiles <= 0) return false;
+    int S = ncu / tiles;
+    if (S > 8) S = 8;
+    if (S > nt / 4) S = nt / 4;                 // at least four k tiles per slice
+    if (S < 2) return false;
+    int ks = (nt + S - 1) / S;
+    ks += ks & 1;                               // whole pairs of k tiles
+    S = (nt + ks - 1) / ks;
+    if (S < 2) return false;
+    *ksplit = ks;
+    *nslices = S;
+    return true;
+}
+
 int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % BM || g.N % BN || g.K % BK) return MHMR_ERR_BAD_SHAPE;
     if (g.lda % 8 || g.ldw % 8) return MHMR_ERR_BAD_SHAPE;
@@ -292,6 +314,7 @@ int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s) {
     if (g.epi == EPI_OP16_QK && g.N % 128) return MHMR_ERR_BAD_SHAPE;      // Q | K halves are whole 64-column blocks
     if (g.lo8 && (g_force_gemm128 || !mhmr_gemm256_eligible(g))) return MHMR_ERR_BAD_SHAPE;      // fp8 low-half range: 256x256 kernel only
     if ((g.x8_off > 0 || g.ldx16 > 0) && !g.x16) return MHMR_ERR_BAD_ARG;
+    if (g.ksplit > 0 && (g_force_gemm128 || !mhmr_gemm256_eligible(g))) return MHMR_ERR_BAD_SHAPE;   // split-k: 256x256 kernel only
     if (g.x16 || g.pstats || g.rowstats) {       // LayerNorm fold: 256x256 kernel only
         if (g_force_gemm128 || !mhmr_gemm256_eligible(g)) return MHMR_ERR_BAD_SHAPE;
         if (g.rowstats && g.K < 256) return MHMR_ERR_BAD_SHAPE;      // (the strip DMA of a tile needs a barrier-separated k pair in front of it)
@@ -315,7 +338,7 @@ int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s) {
         // column-group order (gemm256.hip): MHMR_COLGROUP = "a[,b]" panels per group for N = 2048 (QK) [, N >= 4096 (fc1)]; 0 = off, 1 = 4
         static const ColGroupEnv cge;
         const int nbn = g.N / 256;
-        g2.colgroup = nbn >= 16 ? cge.wide : cge.narrow;
+        g2.colgroup = g.ksplit > 0 ? 0 : nbn >= 16 ? cge.wide : cge.narrow;
         // image of a row tile = umulhi(tm, magic), exact while tm * tiles_per_image < 2^32; one tile per image: magic 0 = identity
         if (g.img_rows > 256) g2.img_magic = (unsigned)((1ull << 32) / (unsigned)(g.img_rows >> 8)) + 1u;
         rc = mhmr_launch_gemm256(g2, dtype, s);

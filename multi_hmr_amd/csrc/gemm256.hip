@@ -114,8 +114,13 @@ __device__ int g_gemm_sametile;      // 1: every tile reads the operands of tile
 // LO8 (GemmArgs::lo8): the k tiles behind a_k are fp8 tiles of 128 k.  A lane's two 16-byte fragments of a row (k steps 0 and 1 of a 16-bit
 // tile) are exactly the 32 bytes v_mfma_scale_f32_16x16x128_f8f6f4 wants from it (which 32 of the row's 128 k a lane holds is a permutation
 // of k applied to both operands alike), so the ring, the copies and the fragment reads are those of the 16-bit tiles: only the MFMA differs.
-template <int DT, int EPI, bool FOLD = false, bool LO8 = false>
+// SPLITK (GemmArgs::ksplit; EPI_F32 only): a SHORT launch -- fewer tiles than half the CUs: the residual linears of a batch of one -- walks
+// VIRTUAL tiles (k slice, tile): slice s covers the k tiles [s * ksplit, min((s + 1) * ksplit, K / 64)) and writes its fp32 partial tile into
+// slab s of `out` ([nslices][M][ldo]); the slices of one tile are summed in slice order by the kernel that follows (vit_misc.hip:
+// splitk_resid_kernel, which also runs the residual epilogue and leaves the row statistics) -- deterministic, no inter-workgroup hand-off.
+template <int DT, int EPI, bool FOLD = false, bool LO8 = false, bool SPLITK = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
+    static_assert(!SPLITK || (EPI == EPI_F32 && !FOLD && !LO8), "split-k: fp32 partial tiles only");
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
     typedef typename Op<DT>::V4 V4;
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     const int ldp = ROWMAJOR ? g.ldw : g.lda, ldq = ROWMAJOR ? g.lda : g.ldw;
 
     // ---- persistent tile walk: XCD x owns a contiguous run of G/8 tiles in every round (neighbouring tiles share an L2) ----
-    const int nbn = g.N / 256, ntiles = (g.M / 256) * nbn;
+    const int nbn = g.N / 256, ntiles_real = (g.M / 256) * nbn, ntiles = SPLITK ? ntiles_real * g.nslices : ntiles_real;
     const int G = gridDim.x, b = blockIdx.x;
     const int first = (G & 7) == 0 ? (b & 7) * (G >> 3) + (b >> 3) : b;
     // Column-group order (wide outputs: QK N = 2048, fc1 N = 4096): an XCD keeps the SAME four weight column panels in every round
@@ -158,7 +163,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     // p0 / q0: LOGICAL first index of the tile on the P / Q side; ar: PHYSICAL first row of its activation rows (GemmArgs::img_rows)
     // (the image of a row tile by a host-made reciprocal, GemmArgs::img_magic: a run-time integer division here costs a dozen live
     // vector registers in a kernel that has none to spare)
-    auto tile_src = [&](int tix, const T*& pb, const T*& qb, int& p0, int& q0, int& ar, int& bimg) {
+    auto tile_src = [&](int tix, const T*& pb, const T*& qb, int& p0, int& q0, int& ar, int& bimg, [[maybe_unused]] int& slc) {
+        if constexpr (SPLITK) {          // virtual tile = slice * ntiles_real + tile (slice-major: neighbouring CUs share a slice's operand panels)
+            slc = 0;
+            while (tix >= ntiles_real) { tix -= ntiles_real; ++slc; }
+        }
 #ifdef MHMR_GEMM_STAMPS
         if (g_gemm_sametile == 1) tix = 0;
         if (g_gemm_sametile == 2) tix = (int)blockIdx.x;
@@ -283,6 +292,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
 
     const T *p_src, *q_src, *p_nxt, *q_nxt;
     int p0, q0, p0n, q0n, ar, arn, bimg, bimgn;
+    [[maybe_unused]] int sl = 0, sln = 0;          // SPLITK: the k slice of this / the next virtual tile
     if (first >= ntiles) return;             // (never with the launcher's grid: G <= ntiles; keeps barrier counts trivially equal)
     if (g.stagger_ticks > 0) {       // CU quarters start 0/1/2/3 x stagger_ticks late so their epilogue bursts interleave (gemm.hip)
         const uint64_t t0 = wall_clock64(), dl = (uint64_t)g.stagger_ticks * (uint64_t)(first * 4 / G);
@@ -302,17 +312,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         }
         return first + r * G;
     };
-    tile_src(tile_of(0), p_src, q_src, p0, q0, ar, bimg);
+    tile_src(tile_of(0), p_src, q_src, p0, q0, ar, bimg, sl);
+    // SPLITK: first k tile of this tile's slice (kb; kbn = the next tile's) and its number of k tiles (ntc); otherwise 0 / 0 / nt
+    int kb = 0, kbn = 0, ntc = nt;
+    if constexpr (SPLITK) { kb = sl * g.ksplit; ntc = nt - kb < g.ksplit ? nt - kb : g.ksplit; }
 
     // ---- prologue (first tile only): K tile 0 -> even buffer (all four halves), K tile 1 -> odd buffer (Q1, P0, Q0; P1 follows
     //      in phase 1 like in every later pair) ----
-    dma(q_src, q_lane, ldq, 0, 0, SLOT_Q0);
-    dma(p_src, p_lane, ldp, 0, 0, SLOT_P0);
-    dma(q_src, q_lane, ldq, 1, 0, SLOT_Q1);
-    dma(p_src, p_lane, ldp, 1, 0, SLOT_P1);
-    dma(q_src, q_lane, ldq, 1, 1, BUF + SLOT_Q1);
-    dma(p_src, p_lane, ldp, 0, 1, BUF + SLOT_P0);
-    dma(q_src, q_lane, ldq, 0, 1, BUF + SLOT_Q0);
+    {
+        // (the activation side -- Q for row-major outputs -- wraps around at nta k tiles; a slice may start behind the wrap)
+        const int k0p = !SPLITK ? 0 : ROWMAJOR ? kb : ka(kb), k1p = !SPLITK ? 1 : ROWMAJOR ? kb + 1 : ka(kb + 1);
+        const int k0q = !SPLITK ? 0 : ROWMAJOR ? ka(kb) : kb, k1q = !SPLITK ? 1 : ROWMAJOR ? ka(kb + 1) : kb + 1;
+        dma(q_src, q_lane, ldq, 0, k0q, SLOT_Q0);
+        dma(p_src, p_lane, ldp, 0, k0p, SLOT_P0);
+        dma(q_src, q_lane, ldq, 1, k0q, SLOT_Q1);
+        dma(p_src, p_lane, ldp, 1, k0p, SLOT_P1);
+        dma(q_src, q_lane, ldq, 1, k1q, BUF + SLOT_Q1);
+        dma(p_src, p_lane, ldp, 0, k1p, BUF + SLOT_P0);
+        dma(q_src, q_lane, ldq, 0, k1q, BUF + SLOT_Q0);
+    }
 #pragma unroll
     for (int a = 0; a < 8; ++a) acc_init(a >> 2, (a >> 1) & 1, a & 1, p0, q0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -324,14 +342,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         rdQ(QA, 0, SLOT_Q0);
         if (wp == 1) { MHMR_SYNC(); }       // stagger: during the K loop group 1 runs one barrier behind group 0
         const bool has_next = r + 1 < nmine;
-        if (has_next) tile_src(tile_of(r + 1), p_nxt, q_nxt, p0n, q0n, arn, bimgn);
-        else { p_nxt = p_src; q_nxt = q_src; p0n = p0; q0n = q0; arn = ar; bimgn = bimg; }     // last tile: harmless re-load into slots nobody reads
+        if (has_next) tile_src(tile_of(r + 1), p_nxt, q_nxt, p0n, q0n, arn, bimgn, sln);
+        else { p_nxt = p_src; q_nxt = q_src; p0n = p0; q0n = q0; arn = ar; bimgn = bimg; sln = sl; }     // last tile: harmless re-load into slots nobody reads
+        if constexpr (SPLITK) kbn = sln * g.ksplit;
         auto kpair = [&](int t, auto lowc) {
             // K-tile indices past the end of this tile are the first K tiles of the next one
-            const bool wrap = t + 2 >= nt;
+            // (t counts this tile's k tiles, 0 .. ntc - 1; the copies take ABSOLUTE k-tile indices: + kb / kbn, both 0 unless SPLITK)
+            const bool wrap = t + 2 >= ntc;
             const T* p2 = wrap ? p_nxt : p_src;
             const T* q2 = wrap ? q_nxt : q_src;
-            const int t1 = t + 1, t2 = wrap ? (has_next ? 0 : nt - 1) : t + 2, t3 = wrap ? (has_next ? 1 : nt - 1) : t + 3;
+            const int t1 = kb + t + 1, t2 = wrap ? (has_next ? kbn : kb + ntc - 1) : kb + t + 2, t3 = wrap ? (has_next ? kbn + 1 : kb + ntc - 1) : kb + t + 3;
             // the activation side (Q for row-major outputs, P for V^T) wraps around at nta k tiles (low-half weight pass)
             const int t1p = ROWMAJOR ? t1 : ka(t1), t2p = ROWMAJOR ? t2 : ka(t2), t3p = ROWMAJOR ? t3 : ka(t3);
             const int t2q = ROWMAJOR ? ka(t2) : t2, t3q = ROWMAJOR ? ka(t3) : t3;
@@ -384,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
             MHMR_SYNC(); mma(acc[1][1], QB, lowc); MHMR_SYNC();
         };
         // the 16-bit k tiles, then (LO8) the fp8 k tiles behind a_k: whole pairs either way (a_k % 256 == 0)
-        for (int t = 0; t < (LO8 ? nta : nt); t += 2) kpair(t, std::false_type{});
+        for (int t = 0; t < (LO8 ? nta : ntc); t += 2) kpair(t, std::false_type{});
         if constexpr (LO8)
             for (int t = nta; t < nt; t += 2) kpair(t, std::true_type{});
 
@@ -590,7 +610,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                                     *(f32x4*)((float*)g.out + ((size_t)bi * g.Tp + n_in) * g.ldo + n) = v;      // class token LAST: patch n at row n
                                 }
                             } else {
-                                *(f32x4*)((float*)g.out + (size_t)(qphys + 16 * qs + row) * g.ldo + n) = v;
+                                if constexpr (SPLITK) *(f32x4*)((float*)g.out + ((size_t)sl * g.M + (size_t)(qphys + 16 * qs + row)) * g.ldo + n) = v;
+                                else *(f32x4*)((float*)g.out + (size_t)(qphys + 16 * qs + row) * g.ldo + n) = v;
                             }
                         }
                     }
@@ -604,6 +625,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         GEMM_STAMP(r, 4);
         p_src = p_nxt; q_src = q_nxt; p0 = p0n; q0 = q0n; ar = arn; bimg = bimgn;
+        if constexpr (SPLITK) { sl = sln; kb = kbn; ntc = nt - kb < g.ksplit ? nt - kb : g.ksplit; }
     }
 #undef MHMR_SYNC
 #undef MHMR_WAIT_DMA
@@ -618,28 +640,34 @@ namespace {
 
 template <int DT>
 int launch256_dt(const GemmArgs& g, hipStream_t s) {
-    const int ntiles = (g.M / 256) * (g.N / 256);
+    const int ntiles = (g.M / 256) * (g.N / 256) * (g.ksplit > 0 ? g.nslices : 1);      // (split-k: virtual tiles)
     const int ncu = mhmr_cu_count();                   // of the CURRENT device
     if (ncu <= 0) return MHMR_ERR_BAD_ARG;
     const int grid = ntiles < ncu ? ntiles : ncu;      // one persistent block per CU
     // 160 KiB of dynamic LDS: the attribute is per device (DeviceOnce, mhmr_internal.h)
-#define MHMR_GEMM_LAUNCH8(E, F, L8)                                                                            \
+#define MHMR_GEMM_LAUNCH9(E, F, L8, SK)                                                                        \
     {                                                                                                          \
         static DeviceOnce once;                                                                                \
         int dev = 0;                                                                                           \
         const int need = once.need(&dev);                                                                      \
         if (need == -2) return MHMR_ERR_BAD_ARG;                                                               \
         if (need >= 0) {                                                                                       \
-            hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DT, E, F, L8>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DT, E, F, L8, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                LDS_BYTES);                                                     \
             if (e != hipSuccess) return (int)e;                                                                \
             once.mark(dev);                                                                                    \
         }                                                                                                      \
-        hipLaunchKernelGGL((gemm256_kernel<DT, E, F, L8>), dim3(grid), dim3(512), LDS_BYTES, s, g);            \
+        mhmr_launch_kernel(gemm256_kernel<DT, E, F, L8, SK>, dim3(grid), dim3(512), LDS_BYTES, s, g);          \
     }
+#define MHMR_GEMM_LAUNCH8(E, F, L8) MHMR_GEMM_LAUNCH9(E, F, L8, false)
 #define MHMR_GEMM_LAUNCH(E, F) MHMR_GEMM_LAUNCH8(E, F, false)
 #define MHMR_GEMM_CASE(E) \
     case E: MHMR_GEMM_LAUNCH(E, false) break;
+    if (g.ksplit > 0) {                     // split-k: fp32 partial tiles of a short launch (eligibility: mhmr_gemm256_eligible)
+        MHMR_GEMM_LAUNCH9(EPI_F32, false, false, true)
+        MHMR_CHECK_LAUNCH();
+        return 0;
+    }
     if (g.lo8) {                            // fp8 low-half range: the V^T projection (plain or folded) and the residual projection
         if (g.epi == EPI_VT && g.rowstats != nullptr) MHMR_GEMM_LAUNCH8(EPI_VT, true, true)
         else if (g.epi == EPI_VT) MHMR_GEMM_LAUNCH8(EPI_VT, false, true)
@@ -673,6 +701,7 @@ int launch256_dt(const GemmArgs& g, hipStream_t s) {
 #undef MHMR_GEMM_CASE
 #undef MHMR_GEMM_LAUNCH
 #undef MHMR_GEMM_LAUNCH8
+#undef MHMR_GEMM_LAUNCH9
     MHMR_CHECK_LAUNCH();
     return 0;
 }
@@ -687,6 +716,12 @@ bool mhmr_gemm256_eligible(const GemmArgs& g) {
         if (g.a_k <= 0 || g.a_k % 256 || g.K != g.a_k + g.a_k / 2 || g.lda < g.K || g.ldw < g.K || !(g.epi == EPI_VT || g.epi == EPI_RESID)) return false;
     } else if (g.a_k > 0 && (g.a_k % 128 || (g.K != 2 * g.a_k && g.K != 3 * g.a_k))) return false;
     if (g.lda >= (1 << 22) || g.ldw >= (1 << 22)) return false;      // 32-bit operand offsets INSIDE a 256-row tile (tile bases are 64-bit)
+    if (g.ksplit > 0) {        // split-k: whole PAIRS of k tiles per slice, the last slice included; fp32 partials, no bias, no row map
+        const int nt = g.K / 64;
+        if (g.epi != EPI_F32 || g.bias || g.lo8 || g.img_rows > 0 || g.ksplit % 2 || g.nslices < 2 || g.nslices > 16 ||
+            (g.nslices - 1) * g.ksplit >= nt || g.nslices * g.ksplit < nt || g.ldo != g.N)
+            return false;
+    }
     return g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && (g.epi != EPI_VT || g.Tp % 64 == 0);
 }
 

@@ -58,6 +58,9 @@ struct GemmArgs {
     const float* rowstats = nullptr;
     const float* colsum = nullptr;
     const float* fbias = nullptr;
+    // Split-k (gemm256 only, EPI_F32, no bias): ksplit > 0 = k tiles (of 64) per slice, nslices slices; slice s writes its fp32 partial
+    // product into out + s * M * ldo (ldo == N).  For launches of fewer tiles than half the CUs (mhmr_splitk_plan, capi.hip).
+    int ksplit = 0, nslices = 0;
 };
 
 // physical row of logical activation row m (see GemmArgs::img_rows)
@@ -85,6 +88,20 @@ struct DeviceOnce {
 };
 // multiProcessorCount of the CURRENT device (cached per device id)
 int mhmr_cu_count();
+
+// "Any-order" launches (hipExtAnyOrderLaunch: the AQL packet goes out WITHOUT the barrier bit, so the command processor does not wait for
+// the previous kernel of the stream to finish before dispatching this one).  capi.hip sets the thread-local flag around launches whose
+// inputs were complete before the PREVIOUS launch started and whose outputs nothing touches until the next ordinary launch (which waits
+// for everything before it): the V projection behind the Q | K projection, the class-row linears behind the big GEMM of the same
+// linear.  Their workgroups then start on the CUs the persistent GEMM in front of them frees first, i.e. inside its tail, instead of
+// behind its last workgroup.  MHMR_ANYORDER=0 switches it off (A/B measurements); never set while a stream is being captured.
+extern thread_local int g_mhmr_anyorder;
+#include <hip/hip_ext.h>
+template <typename F, typename... Args>
+inline void mhmr_launch_kernel(F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args) {
+    if (g_mhmr_anyorder) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, s, nullptr, nullptr, hipExtAnyOrderLaunch, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
+}
 
 // ---- per-kernel-family hipEvent profiling (bench.py roofline leg) ----
 enum ProfKind { PROF_GEMM = 0, PROF_ATTN = 1, PROF_LBS = 2, PROF_KINDS = 3 };

@@ -129,9 +129,9 @@ template <int DT, int U, int NW>
 int launch_cls_u(const ClsArgs& a, int epi, hipStream_t s) {
     const dim3 grid(a.N / 16, (a.B + 31) / 32);
     switch (epi) {
-        case CLS_QKV: hipLaunchKernelGGL((cls_linear_kernel<DT, CLS_QKV, U, NW>), grid, dim3(64 * NW), 0, s, a); break;
-        case CLS_RESID: hipLaunchKernelGGL((cls_linear_kernel<DT, CLS_RESID, U, NW>), grid, dim3(64 * NW), 0, s, a); break;
-        case CLS_GELU: hipLaunchKernelGGL((cls_linear_kernel<DT, CLS_GELU, U, NW>), grid, dim3(64 * NW), 0, s, a); break;
+        case CLS_QKV: mhmr_launch_kernel(cls_linear_kernel<DT, CLS_QKV, U, NW>, grid, dim3(64 * NW), 0, s, a); break;
+        case CLS_RESID: mhmr_launch_kernel(cls_linear_kernel<DT, CLS_RESID, U, NW>, grid, dim3(64 * NW), 0, s, a); break;
+        case CLS_GELU: mhmr_launch_kernel(cls_linear_kernel<DT, CLS_GELU, U, NW>, grid, dim3(64 * NW), 0, s, a); break;
         default: return MHMR_ERR_BAD_ARG;
     }
     MHMR_CHECK_LAUNCH();

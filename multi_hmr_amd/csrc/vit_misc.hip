@@ -169,6 +169,64 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
     }
 }
 
+// Second half of a split-k residual linear (csrc/gemm256.hip SPLITK; a batch of one: DESIGN.md section 12).  part = [nslices][rows][C] fp32
+// partial products.  One wave per row:  v = sum over the slices IN SLICE ORDER (deterministic) + bias;  r = resid + gamma * v  -> resid (fp32,
+// in place), x16 = the 16-bit copy of the RAW row (the next linear's A operand under the LayerNorm fold) and rowstats[row] = (mean, rstd) of r
+// with the centred variance, two passes in registers like layernorm_kernel -- so no ln_stats launch follows this linear.
+template <int DT, int NP>
+__global__ __launch_bounds__(256) void splitk_resid_kernel(const float* __restrict__ part, int nslices, size_t slab, const float* __restrict__ bias,
+                                                           const float* __restrict__ gamma, float* __restrict__ resid, void* __restrict__ x16_,
+                                                           int ldx, float* __restrict__ rowstats, int rows, float eps) {
+    typedef typename Op<DT>::T T;
+    typedef typename Op<DT>::V4 V4;
+    constexpr int C = NP * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* pp = part + (size_t)row * C;
+    float* rp = resid + (size_t)row * C;
+    f32x4 v[NP], r[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = *(const f32x4*)(pp + c);
+        r[i] = *(const f32x4*)(rp + c);
+    }
+    for (int sidx = 1; sidx < nslices; ++sidx) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) v[i] += *(const f32x4*)(pp + (size_t)sidx * slab + (i * 64 + lane) * 4);
+    }
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        const f32x4 b4 = bias ? *(const f32x4*)(bias + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 g4 = gamma ? *(const f32x4*)(gamma + c) : (f32x4){1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            r[i][e] = r[i][e] + g4[e] * (v[i][e] + b4[e]);
+            s1 += r[i][e];
+        }
+        *(f32x4*)(rp + c) = r[i];
+        if (x16_) {
+            V4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (T)r[i][e];
+            *(V4*)((T*)x16_ + (size_t)row * ldx + c) = o;
+        }
+    }
+    if (rowstats) {
+        const float mean = wave_sum(s1) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float dlt = r[i][e] - mean; q += dlt * dlt; }
+        const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + eps);
+        if (lane == 0) *(f32x2*)(rowstats + (size_t)row * 2) = (f32x2){mean, rstd};
+    }
+}
+
 // exact-erf GELU of an fp32 matrix [M, N] -> the op16 pair [M, 2 N] = [hi | lo] (the f16x3 mode's fc2 operand); 4 values per thread
 template <int DT>
 __global__ __launch_bounds__(256) void gelu_pair_kernel(const float* __restrict__ in, void* __restrict__ out_, long long total4, int N) {
@@ -250,6 +308,33 @@ int mhmr_launch_gelu_pair(const float* in, void* out, long long M, int N, int dt
     const int grid = (int)((total4 + 255) / 256);
     if (dtype == MHMR_DT_F16) hipLaunchKernelGGL((gelu_pair_kernel<MHMR_DT_F16>), dim3(grid), dim3(256), 0, s, in, out, total4, N);
     else hipLaunchKernelGGL((gelu_pair_kernel<MHMR_DT_BF16>), dim3(grid), dim3(256), 0, s, in, out, total4, N);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+int mhmr_launch_splitk_resid(const float* part, int nslices, int rows, int C, const float* bias, const float* gamma, float* resid, void* x16,
+                             int ldx, float* rowstats, float eps, int dtype, hipStream_t s) {
+    if (nslices < 1 || rows <= 0 || (x16 && ldx < C)) return MHMR_ERR_BAD_ARG;
+    const size_t slab = (size_t)rows * C;
+    const int grid = (rows + 3) / 4;
+#define SK_CASE(CV, NPV)                                                                                                                   \
+    case CV:                                                                                                                               \
+        if (dtype == MHMR_DT_F16)                                                                                                          \
+            hipLaunchKernelGGL((splitk_resid_kernel<MHMR_DT_F16, NPV>), dim3(grid), dim3(256), 0, s, part, nslices, slab, bias, gamma, resid, x16, \
+                               ldx, rowstats, rows, eps);                                                                                  \
+        else                                                                                                                               \
+            hipLaunchKernelGGL((splitk_resid_kernel<MHMR_DT_BF16, NPV>), dim3(grid), dim3(256), 0, s, part, nslices, slab, bias, gamma, resid, x16, \
+                               ldx, rowstats, rows, eps);                                                                                  \
+        break;
+    switch (C) {
+        SK_CASE(256, 1)
+        SK_CASE(512, 2)
+        SK_CASE(768, 3)
+        SK_CASE(1024, 4)
+        default:
+            return MHMR_ERR_BAD_SHAPE;
+    }
+#undef SK_CASE
     MHMR_CHECK_LAUNCH();
     return 0;
 }

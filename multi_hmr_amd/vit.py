@@ -337,6 +337,12 @@ class WorkspaceCache:
                          attn_flags=z(_lib.lib().mhmr_attention_flag_count(Bh, Tp, H), dtype=torch.int32))
             if P.get("fold"):
                 b.update(pstats=z(Bh * Tp, Cd // 64, 2, dtype=torch.float32), rowstats=z(Bh * Tp, 2, dtype=torch.float32))
+            # split-k residual linears (csrc/capi.hip): only the all-rows form of a tiny batch has launches short enough to be split
+            skb = 0
+            if P.get("fold") and not x3 and not P.get("lo8") and Tp % 256 == 0 and not row_map(P, Bh):
+                skb = max(_lib.lib().mhmr_splitk_workspace_bytes(Bh * Tp, Cd, kk) for kk in (Cd, 2 * Cd, 4 * Cd))
+            if skb:
+                b["splitk"] = z(skb // 4, dtype=torch.float32)
             d = _lib.VitDesc()
             d.dtype, d.B, d.S, d.C, d.H, d.L = P["dt_id"], Bh, P["S"], Cd, H, P["L"]
             d.G, d.N, d.T, d.Tp, d.Kp = P["G"], N, P["T"], Tp, P["Kp"]
@@ -349,6 +355,7 @@ class WorkspaceCache:
             d.lo8 = 1 if (P.get("lo8") and not x3) else 0
             d.pstats = b["pstats"].data_ptr() if P.get("fold") else None
             d.rowstats = b["rowstats"].data_ptr() if P.get("fold") else None
+            d.splitk, d.splitk_bytes = (b["splitk"].data_ptr(), skb) if skb else (None, 0)
             parts.append(dict(desc=d, B=Bh, img0=i * Bh, bufs=b))
         ws = dict(parts[0]["bufs"])
         ws["feat32"] = z(B * N, Cd, dtype=torch.float32)

@@ -843,3 +843,55 @@ def test_attention_and_layernorm_with_a_row_pitch_and_the_bf8_copy(L):
     y8 = o2.view(torch.uint8).reshape(rows, 2 * p2)[:, 2 * Cl:3 * Cl].contiguous().view(torch.float8_e5m2).float()
     ref = torch.nn.functional.layer_norm(x, (Cl,), w, b, 1e-6)
     assert float(((y8 - ref).abs() <= 0.13 * ref.abs() + 1e-4).float().mean()) > 0.9999
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("M,N,K,a_k", [(4352, 1024, 4096, 0),      # fc2 of multiHMR_896_L at batch 1: 68 tiles -> 3 slices of 22 / 22 / 20 k tiles
+                                        (4352, 1024, 2048, 1024),   # its output projection with the low-half k range: 12 / 12 / 8, one slice straddles the wrap
+                                        (2560, 1024, 1024, 0),      # 672^2: 40 tiles -> 4 slices of 4 k tiles
+                                        (2560, 768, 3072, 0),       # ViT-B: 30 tiles -> 8 slices of 6
+                                        (256, 256, 512, 0)])        # one tile, two slices
+def test_splitk_residual_linear(L, name, dt, tdt, tol, M, N, K, a_k):
+    """mhmr_gemm16_splitk_resid = split-k GEMM (fp32 partial tiles, slices summed in slice order) + the row-wise residual epilogue that also
+    leaves the op16 copy and the (mean, rstd) of every updated row: against fp64 torch, against the unsplit residual linear of the same
+    operands (same products, another summation order), and bit-reproducible."""
+    g = torch.Generator(device=dev()).manual_seed(M + N + K + a_k)
+    ka = a_k if a_k else K
+    A = torch.randn(M, ka, generator=g, device=dev()).to(tdt)
+    W = (torch.randn(N, K, generator=g, device=dev()) / math.sqrt(ka)).to(tdt)
+    if a_k:
+        W[:, a_k:] *= 2.0 ** -11                      # a low half's magnitude
+    bias, gamma = torch.randn(N, generator=g, device=dev()), 0.5 + torch.rand(N, generator=g, device=dev())
+    r0 = torch.randn(M, N, generator=g, device=dev())
+    nbytes = L.mhmr_splitk_workspace_bytes(M, N, K)
+    assert nbytes > 0 and nbytes % (M * N * 4) == 0 and 2 <= nbytes // (M * N * 4) <= 8
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev())
+    outs = []
+    for _ in range(2):
+        r = r0.clone()
+        x16 = torch.zeros(M, N, dtype=tdt, device=dev())
+        st = torch.zeros(M, 2, device=dev())
+        ws.fill_(float("nan"))
+        _lib.check(L.mhmr_gemm16_splitk_resid(A.data_ptr(), ka, W.data_ptr(), K, M, N, K, a_k, bias.data_ptr(), gamma.data_ptr(), r.data_ptr(),
+                                              x16.data_ptr(), 0, st.data_ptr(), 1e-6, ws.data_ptr(), nbytes, dt, stream()), "splitk")
+        outs.append((r, x16, st))
+    (r, x16, st), (r2, x162, st2) = outs
+    assert torch.equal(r, r2) and torch.equal(x16, x162) and torch.equal(st, st2)
+    Aw = torch.cat([A, A], 1) if a_k else A
+    ref = r0.double() + gamma.double() * (Aw.double() @ W.double().T + bias.double())
+    assert rel(r, ref) < 2e-6 and maxrel(r, ref) < 1e-5
+    assert torch.equal(x16, r.to(tdt))
+    mean, var = ref.mean(1), ref.var(1, unbiased=False)
+    assert maxrel(st[:, 0], mean) < 1e-5 and maxrel(st[:, 1], (var + 1e-6).rsqrt()) < 1e-5
+    # the unsplit residual linear: the same fp32 products in another order
+    r3 = r0.clone()
+    _lib.check(L.mhmr_gemm16_ex(A.data_ptr(), ka, W.data_ptr(), K, M, N, K, bias.data_ptr(), gamma.data_ptr(), r3.data_ptr(), N, None, 0, 128, 1,
+                                M, _lib.EPI_RESID, dt, 0, 0, a_k, stream()), "gemm")
+    assert rel(r, r3) < 1e-6
+
+
+def test_splitk_plan_declines_long_launches(L):
+    """A launch that already fills more than half of the CUs, or a k range too short to cut, is not split (0 bytes)."""
+    assert L.mhmr_splitk_workspace_bytes(256 * 129, 1024, 4096) == 0      # 516 tiles
+    assert L.mhmr_splitk_workspace_bytes(4352, 1024, 256) == 0             # four k tiles
+    assert L.mhmr_splitk_workspace_bytes(4352 + 128, 1024, 4096) == 0      # M not a multiple of 256
