@@ -223,6 +223,16 @@ def main():
         else:
             torch.cuda.set_device(local)
             torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+    ranks_seen = 1
+    if world > 1:
+        # the group really spans `world` processes: an all-reduce of ones (a silent group-of-one fallback would report N x one GPU's rate)
+        one = torch.ones(1, device=torch.device("cpu") if stub else torch.device("cuda", local))
+        torch.distributed.all_reduce(one)
+        ranks_seen = int(one.item())
+        if ranks_seen != world:
+            if rank == 0:
+                print(json.dumps({"error": f"all_reduce of ones over the process group gave {ranks_seen}, expected {world}", "n_gpus": args.gpus}))
+            sys.exit(2)
     if world != args.gpus:
         if rank == 0:
             print(json.dumps({"error": f"--gpus {args.gpus} but WORLD_SIZE={world}", "n_gpus": args.gpus}))
@@ -308,11 +318,14 @@ def main():
         "mfma_utilisation_whole_forward": round((gemm_fl + attn_fl) * B * args.steps / dt / 1e12 / PEAK_MFMA_TFLOPS, 4),
         "lib_sha16": None if stub else lib_sha16(), "source_hash": None if stub else lib_source_hash(),
         "backbone_image_blocks": model._nsplit(B),
+        # what Model(precision=...) resolved to at pack time ("auto" -> "f16" | "f16x3" from the weights; the bench asks for args.dtype)
+        "precision_resolved": None if stub else model.packed_precision,
     }
     if world > 1:
         result["multi_gpu"] = {"max_rank_compute_ms_per_step": round(compute_ms / args.steps, 3),
                                "exposed_collation_ms_per_step": round(ms_step - compute_ms / args.steps, 3),
-                               "collation": "async RCCL all_gather of counts + padded person records, overlapped with the next step"}
+                               "collation": "async RCCL all_gather of counts + padded person records, overlapped with the next step",
+                               "ranks_verified_by_all_reduce": ranks_seen}
 
     if rank == 0 and stub:
         # stub mode: rank 0's extra passes are a few more calls of the stand-in (the other ranks wait at the barrier below)

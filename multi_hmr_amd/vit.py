@@ -158,6 +158,16 @@ def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = N
          "S": img_size, "device": device, "precision": precision, "precision_requested": requested, "x3": x3}
     if requested == "auto" or x3:
         P["logit_gain"] = logit_gain(enc)
+    if requested == "auto" and x3:
+        # the slow mode was chosen FOR the caller: say so once per pack (a checkpoint that trips the rule runs ~4x slower than plain f16
+        # and allocates two fp32 workspaces of B x Tp x 3C / 4C; advisor finding of round 5)
+        import warnings
+        warnings.warn(f"multi_hmr_amd: precision='auto' resolved to 'f16x3' for this checkpoint: steepest attention-logit spread "
+                      f"{max(P['logit_gain']):.2f} > {LOGIT_GAIN_LIMIT} (vit.logit_gain; per block: min {min(P['logit_gain']):.2f}, "
+                      f"mean {sum(P['logit_gain']) / len(P['logit_gain']):.2f}).  f16 operand pairs with three products per term and an fp32 "
+                      f"attention keep the 1e-3 contract on such weights at about 4x the time of plain f16; Model(precision='f16') forces "
+                      f"the fast path (tools/checkpoint_report.py and tools/parity_table.py say what that costs on these weights).",
+                      RuntimeWarning, stacklevel=3)
     pos = torch.from_numpy(packing.interpolate_pos_embed(enc.pos_embed.detach().float().cpu().numpy(), G)).to(device)
     cls_pos0 = f32(enc.cls_token.reshape(-1)) + pos[0]
     pw = torch.zeros(Cd, P["Kp"], dtype=torch.float32, device=device)

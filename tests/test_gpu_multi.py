@@ -36,6 +36,14 @@ def _rank_main(rank, world, port, out_path):
     dev = torch.device("cuda", rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     try:
+        # the group really has `world` ranks on `world` different GPUs: a silent single-rank fallback (every rank its own group of one)
+        # would pass every comparison below against its own unsharded run
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        ids = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([torch.cuda.current_device()], device=dev))
+        assert dist.get_world_size() == world and float(ones.item()) == float(world), (dist.get_world_size(), float(ones.item()))
+        assert sorted(int(i.item()) for i in ids) == list(range(world)), ids
         cfg = dict(make_golden.CASES["vits_448_infer"], batch=5)          # 5 images over 2 ranks: 3 + 2
         gold = np.load(os.path.join(GOLD, "vits_448_infer.npz"))
         sd = make_golden.case_state_dict(cfg)
@@ -62,7 +70,7 @@ def _rank_main(rank, world, port, out_path):
         ok_async = gimg.tolist() == wimg.tolist() and all(
             float((got[k] - torch.stack([h[k] for h in whole])).abs().max()) == 0.0 for k in ("v3d", "scores", "rotvec"))
         if rank == 0:
-            torch.save(dict(ok=bool(ok), worst=worst, ok_async=bool(ok_async), n=len(humans)), out_path)
+            torch.save(dict(ok=bool(ok), worst=worst, ok_async=bool(ok_async), n=len(humans), ranks=int(ones.item())), out_path)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -74,7 +82,7 @@ def test_forward_sharded_over_rccl_two_ranks(tmp_path):
     out = str(tmp_path / "res.pt")
     mp.spawn(_rank_main, args=(2, _free_port(), out), nprocs=2, join=True)
     res = torch.load(out)
-    assert res["ok"] and res["n"] > 0, res
+    assert res["ok"] and res["n"] > 0 and res["ranks"] == 2, res
     # sharding changes nothing: every kernel is batch-invariant, the collation moves fp32 records
     assert res["worst"] == 0.0, res
     assert res["ok_async"], res

@@ -341,6 +341,18 @@ def test_logit_gain_statistic_and_the_auto_precision_rule():
         assert (gains[0] > vit.LOGIT_GAIN_LIMIT) == hostile, gains
         assert vit.resolve_precision(enc, "auto") == ("f16x3" if hostile else "f16")
         assert vit.resolve_precision(enc, "bf16") == "bf16" and vit.resolve_precision(enc, "fp16") == "f16"
+        # 'auto' choosing the slow mode FOR the caller is said out loud, once per pack, with the statistic and the way to force f16;
+        # an explicit choice and the fast resolution are silent
+        import warnings
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            P = vit.pack_encoder(enc, 224, "auto", "cpu")
+            vit.pack_encoder(enc, 224, "f16x3" if hostile else "f16", "cpu")
+        said = [str(w.message) for w in rec if issubclass(w.category, RuntimeWarning) and "f16x3" in str(w.message)]
+        assert len(said) == (1 if hostile else 0), said
+        assert P["precision"] == ("f16x3" if hostile else "f16")
+        if hostile:
+            assert "precision='f16'" in said[0] and f"{max(gains):.2f}" in said[0]
     with pytest.raises(ValueError):
         vit.resolve_precision(enc, "fp8")
 
