@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define MHMR_VERSION 105   /* 105: mhmr_vit_desc.{splitk, splitk_bytes}, mhmr_splitk_workspace_bytes, mhmr_gemm16_splitk_resid: split-k residual linears for launches that fill less than half the chip (a batch of one); 104: mhmr_vit_desc.{x3, qkv32, hid32}: the f16x3 precision mode (three 16-bit products per term in every backbone linear, fp32 attention); mhmr_gemm16_ex a_k with K = 3 a_k; mhmr_attention_f32; 103: mhmr_attention16_ex variant 6 (the default of mhmr_vit_forward); mhmr_camera_embed(num_bands), mhmr_hph_desc.cam_dim; mhmr_lbs_consts.basis16 layout (high halves for k < Kb - 64); mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
+#define MHMR_VERSION 105   /* 105: mhmr_vit_desc.cpad (ViT-S on the 256x256 kernel: C-wide linears as N = 512 with masked columns); mhmr_vit_desc.{splitk, splitk_bytes}, mhmr_splitk_workspace_bytes, mhmr_gemm16_splitk_resid: split-k residual linears for launches that fill less than half the chip (a batch of one); 104: mhmr_vit_desc.{x3, qkv32, hid32}: the f16x3 precision mode (three 16-bit products per term in every backbone linear, fp32 attention); mhmr_gemm16_ex a_k with K = 3 a_k; mhmr_attention_f32; 103: mhmr_attention16_ex variant 6 (the default of mhmr_vit_forward); mhmr_camera_embed(num_bands), mhmr_hph_desc.cam_dim; mhmr_lbs_consts.basis16 layout (high halves for k < Kb - 64); mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
 
 #define MHMR_OK 0
 #define MHMR_ERR_BAD_ARG (-1)
@@ -135,6 +135,12 @@ typedef struct {
      * noise level -- as the all-rows form itself already does. */
     float* splitk;
     long long splitk_bytes;
+    /* C = 384 (ViT-S) on the 256x256 kernel.  cpad = 512 says: Tp % 256 == 0, pstats / rowstats given, and every array indexed by the
+     * output channel of the three C-wide linears is zero-padded to 512 entries -- qkv_w [2C + 512, C] (the V rows are its last C rows + 128
+     * zero rows), qkv_b and qkv_colsum [2C + 512], v_w2 [512, 2C], proj_w / proj_w2 [512, C | 2C], fc2_w [512, 4C], proj_b, ls1, fc2_b,
+     * ls2 [512].  Those linears then run as N = 512 with the last 128 output columns masked (GemmArgs::n_valid), every block linear is
+     * on the 256x256 kernel and the LayerNorm fold applies.  0 = C-wide linears of such a model run on the 128x128 kernel, no fold. */
+    int cpad;
 } mhmr_vit_desc;
 
 /* x: [B,3,S,S] fp32 (ImageNet-normalised).  feat32: [B*N, C] fp32 patch features (token n = y*G + x).
@@ -160,6 +166,13 @@ int mhmr_gemm16_ex(const void* A, int lda, const void* W, int ldw, int M, int N,
 int mhmr_gemm16_ln(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias,
                    const float* gamma, void* out, int ldo, int Tp, int H, int epi, int dtype, int img_rows, int img_stride,
                    int a_k, void* x16, float* pstats, const float* rowstats, const float* colsum, const float* fbias, void* stream);
+/* mhmr_gemm16_ln for an output width that is a multiple of 128 but not of 256 (ViT-S: 384), on the 256x256 kernel: N = n_valid + 128, W
+ * [N, K] and every per-column vector (bias, gamma, colsum, fbias) zero-padded to N entries by the caller; the last 128 columns are
+ * computed and not stored.  epi = MHMR_EPI_RESID (out32 [M, ldo >= n_valid], x16 / pstats [M, n_valid / 64, 2] optional) or MHMR_EPI_VT
+ * (n_valid / 64 heads; rowstats / colsum / fbias optional: the LayerNorm-fold consumer).  M % 256 == 0, K % 128 == 0. */
+int mhmr_gemm16_masked(const void* A, int lda, const void* W, int ldw, int M, int N, int n_valid, int K, int a_k, const float* bias,
+                       const float* gamma, void* out, int ldo, int Tp, int H, int epi, int dtype, void* x16, float* pstats,
+                       const float* rowstats, const float* colsum, const float* fbias, void* stream);
 /* Split-k residual linear (csrc/gemm256.hip SPLITK + csrc/vit_misc.hip splitk_resid_kernel): out32 += gamma * (A . W^T + bias) for a launch
  * that would otherwise occupy at most half of the CUs.  mhmr_splitk_workspace_bytes: bytes of fp32 partial tiles the pair needs for an
  * [M, N] output over K (0 = such a problem is not split: M, N % 256, K % 128, tiles <= CUs / 2, K >= 512).  a_k as in mhmr_gemm16_ex.

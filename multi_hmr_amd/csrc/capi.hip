@@ -182,6 +182,22 @@ int mhmr_gemm16_lo8(const void* A, int lda, const void* W, int ldw, int M, int N
     return mhmr_launch_gemm(g, dtype, (hipStream_t)stream);
 }
 
+// mhmr_gemm16_ln with a masked output width (GemmArgs::n_valid): N = n_valid + 128 padded columns that are computed and not stored
+int mhmr_gemm16_masked(const void* A, int lda, const void* W, int ldw, int M, int N, int n_valid, int K, int a_k, const float* bias,
+                       const float* gamma, void* out, int ldo, int Tp, int H, int epi, int dtype, void* x16, float* pstats,
+                       const float* rowstats, const float* colsum, const float* fbias, void* stream) {
+    GemmArgs g{A, lda, W, ldw, M, N, K, bias, gamma, out, ldo, nullptr, 0, Tp, H, M, epi};
+    g.a_k = a_k;
+    g.n_valid = n_valid;
+    g.x16 = x16;
+    g.pstats = pstats;
+    g.rowstats = rowstats;
+    g.colsum = colsum;
+    g.fbias = fbias;
+    if (n_valid <= 0 || n_valid >= N) return MHMR_ERR_BAD_ARG;
+    return mhmr_launch_gemm(g, dtype, (hipStream_t)stream);
+}
+
 long long mhmr_splitk_workspace_bytes(int M, int N, int K) {
     int ks = 0, S = 0;
     return mhmr_splitk_plan(M, N, K, &ks, &S) ? (long long)S * M * N * 4 : 0;
@@ -340,7 +356,13 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
     static const bool fold_env = !(getenv("MHMR_LNFOLD") && atoi(getenv("MHMR_LNFOLD")) == 0);
     // ... or, without the row map (N not a multiple of 256: 1288^2, 518^2), every block linear on the 256x256 kernel over ALL B * Tp rows
     // (Tp a multiple of 256: vit.padded_tokens): the class and padding rows are rows like any other, with block sums of their own
-    const bool allrows256 = !rowmap && rowmap_env && C % 256 == 0 && M % 256 == 0 && (uint64_t)M * (uint64_t)C * 4u < (1ull << 32);
+    // (C = 384, ViT-S: the three linears whose output is C wide -- V, proj, fc2 -- run as N = Cp = 512 with the last 128 columns masked,
+    // GemmArgs::n_valid; the caller says with mhmr_vit_desc.cpad that their weights and per-column vectors are zero-padded for it)
+    const int Cp = (C + 255) / 256 * 256;
+    const bool allrows256 = !rowmap && rowmap_env && (C % 256 == 0 || (C % 128 == 0 && d->cpad == Cp)) && M % 256 == 0 &&
+                            (uint64_t)M * (uint64_t)C * 4u < (1ull << 32);
+    const bool nmask = allrows256 && C % 256 != 0;
+    auto masked = [&](GemmArgs& g) { if (nmask) { g.N = Cp; g.n_valid = C; } };
     const bool fold = (rowmap || allrows256) && fold_env && d->pstats && d->rowstats;
     auto ln_stats = [&]() { return rowmap ? mhmr_launch_ln_stats(d->pstats, d->resid, d->rowstats, B, N, Tp, C, 1e-6f, s)
                                           : mhmr_launch_ln_stats(d->pstats, d->resid, d->rowstats, 1, M, M, C, 1e-6f, s); };
@@ -372,7 +394,7 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
     auto resid_linear = [&](GemmArgs& g) -> int {
         int ks = 0, S = 0;
         stats_fresh = false;
-        if (allrows256 && fold && d->splitk && !g.lo8 && g.x16 && g.ldx16 == 0 && mhmr_splitk_plan(g.M, g.N, g.K, &ks, &S) &&
+        if (allrows256 && fold && d->splitk && !g.lo8 && g.n_valid == 0 && g.x16 && g.ldx16 == 0 && mhmr_splitk_plan(g.M, g.N, g.K, &ks, &S) &&
             (long long)S * g.M * g.N * 4 <= d->splitk_bytes) {
             GemmArgs gs{g.A, g.lda, g.W, g.ldw, g.M, g.N, g.K, nullptr, nullptr, d->splitk, g.N, nullptr, 0, Tp, d->H, g.M, EPI_F32};
             gs.a_k = g.a_k;
@@ -414,6 +436,7 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
             gv.a_k = v_ak;
             if (vlo8) { gv.lo8 = 1; gv.w8_scale = k.v_w8_scale; }
             rows(g); rows(gv);
+            masked(gv);
             if (f1) {
                 g.bias = nullptr; g.rowstats = d->rowstats; g.colsum = k.qkv_colsum; g.fbias = k.qkv_b;
                 gv.bias = nullptr; gv.rowstats = d->rowstats; gv.colsum = k.qkv_colsum + 2 * C; gv.fbias = k.qkv_b + 2 * C;
@@ -442,6 +465,7 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
             if (plo8) { g.lo8 = 1; g.w8_scale = k.proj_w8_scale; }
             rows(g);
             if (fold) { g.x16 = d->xn; g.pstats = d->pstats; g.ldx16 = lo8 ? pit : 0; }
+            masked(g);
             TRY(resid_linear(g));
             AnyOrder ao_scope(ao);
             if (rowmap)
@@ -470,6 +494,7 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
                 g2.x16 = d->xn; g2.pstats = d->pstats; g2.ldx16 = lo8 ? pit : 0;
                 g2.x8_off = (l + 1 < d->L && v8(d->blocks[l + 1])) ? o8 : 0;
             }
+            masked(g2);
             TRY(resid_linear(g2));
             AnyOrder ao_scope2(ao);
             if (rowmap)

@@ -118,9 +118,14 @@ __device__ int g_gemm_sametile;      // 1: every tile reads the operands of tile
 // VIRTUAL tiles (k slice, tile): slice s covers the k tiles [s * ksplit, min((s + 1) * ksplit, K / 64)) and writes its fp32 partial tile into
 // slab s of `out` ([nslices][M][ldo]); the slices of one tile are summed in slice order by the kernel that follows (vit_misc.hip:
 // splitk_resid_kernel, which also runs the residual epilogue and leaves the row statistics) -- deterministic, no inter-workgroup hand-off.
-template <int DT, int EPI, bool FOLD = false, bool LO8 = false, bool SPLITK = false>
+// NMASK (GemmArgs::n_valid; EPI_RESID and EPI_VT only): an output width that is a multiple of 128 but not of 256 (ViT-S: N = 384) runs as
+// N = 512 with the weight rows (and every per-column array: bias, gamma, colsum, fbias) zero-padded by the caller; the 128-column half
+// tiles at or behind n_valid are computed (zeros) and not stored -- 25 % of such a launch's matrix work is padding, at three times the
+// rate the 128x128 kernel reaches on the same shape.
+template <int DT, int EPI, bool FOLD = false, bool LO8 = false, bool SPLITK = false, bool NMASK = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     static_assert(!SPLITK || (EPI == EPI_F32 && !FOLD && !LO8), "split-k: fp32 partial tiles only");
+    static_assert(!NMASK || ((EPI == EPI_RESID || EPI == EPI_VT) && !LO8 && !SPLITK), "masked output halves: residual and V^T epilogues");
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
     typedef typename Op<DT>::V4 V4;
@@ -442,9 +447,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
             // 32-bit byte offsets from the uniform base (eligibility guarantees M * ldo * 4 < 2^32): one VGPR per address
             const uint32_t off0 = ((uint32_t)(ar + 32 * wq + (lane >> 4)) * (uint32_t)g.ldo + (uint32_t)(p0 + 64 * wp + 4 * c)) * 4u;
             const uint32_t rstep = (uint32_t)g.ldo * 16u;          // 4 rows
+            // NMASK: the 128-column half h = 1 of the LAST column tile lies behind n_valid (n_valid = N - 128).  Its passes run like any other
+            // -- their residual loads are pointed at half 0's columns (valid memory: no conditional loads, which cost this kernel 392 B of
+            // scratch) -- and only their stores are skipped (wave-uniform branch).
+            [[maybe_unused]] const int nvalid = NMASK ? g.n_valid : g.N;
+            [[maybe_unused]] const bool dead1 = NMASK && p0 + 128 >= nvalid;
+            auto live = [&](int sidx) { return !NMASK || !(dead1 && (sidx >> 2) == 1); };
             auto rptr = [&](int sidx, int it) {
                 const int h = sidx >> 2, j = (sidx >> 1) & 1, qs = sidx & 1;
-                const uint32_t off = off0 + (uint32_t)(32 * j + 4 * qs + it) * rstep + (uint32_t)(512 * h);
+                const uint32_t hoff = NMASK ? (live(sidx) ? (uint32_t)(512 * h) : 0u) : (uint32_t)(512 * h);
+                const uint32_t off = off0 + (uint32_t)(32 * j + 4 * qs + it) * rstep + hoff;
                 return (f32x4*)((char*)g.out + off);
             };
             f32x4 r[8][4];
@@ -465,6 +477,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) *(f32x4*)(wl + l15 * 256 + (((4 * ps + g4) ^ l15) * 16)) = acc[h][j][ps][qs];
                 acc_init(h, j, qs, p0n, q0n);
+                if (!live(sidx)) continue;
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int row = 4 * it + (lane >> 4);
@@ -497,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                         if (c == 0) {
                             const int prow = ar + 128 * j + 32 * wq + 16 * qs + row;
                             const int slot = (p0 + 128 * h + 64 * wp) >> 6;
-                            *(f32x2*)(g.pstats + ((size_t)prow * (g.N >> 6) + slot) * 2) = (f32x2){s1, s2};
+                            *(f32x2*)(g.pstats + ((size_t)prow * (nvalid >> 6) + slot) * 2) = (f32x2){s1, s2};
                         }
                     }
                 }
@@ -520,6 +533,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                 const int pb = p0 + 128 * h + 64 * wp;      // first P index of the block (n for row-major, LOGICAL token row for V^T)
                 const int qb = q0 + 128 * j + 32 * wq;      // first Q index (logical m for row-major, channel for V^T)
                 const int qphys = ar + 128 * j + 32 * wq;   // row-major outputs: physical row of qb
+                if constexpr (NMASK && EPI == EPI_VT) {
+                    // V^T: the Q side is the weight (output channel): half j of this tile lies behind n_valid -> nothing to store
+                    if (q0 + 128 * j >= g.n_valid) {
+                        acc_init(h, j, 0, p0n, q0n);
+                        acc_init(h, j, 1, p0n, q0n);
+                        continue;
+                    }
+                }
                 if constexpr (OUT16) {
                     const float qscale = (EPI == EPI_OP16_QK && pb < (g.N >> 1)) ? MHMR_ATTN_QSCALE : 1.f;   // 64 columns: all Q or all K
 #pragma unroll
@@ -645,26 +666,35 @@ int launch256_dt(const GemmArgs& g, hipStream_t s) {
     if (ncu <= 0) return MHMR_ERR_BAD_ARG;
     const int grid = ntiles < ncu ? ntiles : ncu;      // one persistent block per CU
     // 160 KiB of dynamic LDS: the attribute is per device (DeviceOnce, mhmr_internal.h)
-#define MHMR_GEMM_LAUNCH9(E, F, L8, SK)                                                                        \
+#define MHMR_GEMM_LAUNCH10(E, F, L8, SK, NM)                                                                   \
     {                                                                                                          \
         static DeviceOnce once;                                                                                \
         int dev = 0;                                                                                           \
         const int need = once.need(&dev);                                                                      \
         if (need == -2) return MHMR_ERR_BAD_ARG;                                                               \
         if (need >= 0) {                                                                                       \
-            hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DT, E, F, L8, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DT, E, F, L8, SK, NM>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                LDS_BYTES);                                                     \
             if (e != hipSuccess) return (int)e;                                                                \
             once.mark(dev);                                                                                    \
         }                                                                                                      \
-        mhmr_launch_kernel(gemm256_kernel<DT, E, F, L8, SK>, dim3(grid), dim3(512), LDS_BYTES, s, g);          \
+        mhmr_launch_kernel(gemm256_kernel<DT, E, F, L8, SK, NM>, dim3(grid), dim3(512), LDS_BYTES, s, g);      \
     }
+#define MHMR_GEMM_LAUNCH9(E, F, L8, SK) MHMR_GEMM_LAUNCH10(E, F, L8, SK, false)
 #define MHMR_GEMM_LAUNCH8(E, F, L8) MHMR_GEMM_LAUNCH9(E, F, L8, false)
 #define MHMR_GEMM_LAUNCH(E, F) MHMR_GEMM_LAUNCH8(E, F, false)
 #define MHMR_GEMM_CASE(E) \
     case E: MHMR_GEMM_LAUNCH(E, false) break;
     if (g.ksplit > 0) {                     // split-k: fp32 partial tiles of a short launch (eligibility: mhmr_gemm256_eligible)
         MHMR_GEMM_LAUNCH9(EPI_F32, false, false, true)
+        MHMR_CHECK_LAUNCH();
+        return 0;
+    }
+    if (g.n_valid > 0 && g.n_valid != g.N) {        // masked output halves (N = 384 as 512): residual and V^T epilogues
+        if (g.epi == EPI_RESID && !g.rowstats) MHMR_GEMM_LAUNCH10(EPI_RESID, false, false, false, true)
+        else if (g.epi == EPI_VT && g.rowstats) MHMR_GEMM_LAUNCH10(EPI_VT, true, false, false, true)
+        else if (g.epi == EPI_VT) MHMR_GEMM_LAUNCH10(EPI_VT, false, false, false, true)
+        else return MHMR_ERR_BAD_ARG;
         MHMR_CHECK_LAUNCH();
         return 0;
     }
@@ -702,6 +732,7 @@ int launch256_dt(const GemmArgs& g, hipStream_t s) {
 #undef MHMR_GEMM_LAUNCH
 #undef MHMR_GEMM_LAUNCH8
 #undef MHMR_GEMM_LAUNCH9
+#undef MHMR_GEMM_LAUNCH10
     MHMR_CHECK_LAUNCH();
     return 0;
 }
@@ -716,6 +747,9 @@ bool mhmr_gemm256_eligible(const GemmArgs& g) {
         if (g.a_k <= 0 || g.a_k % 256 || g.K != g.a_k + g.a_k / 2 || g.lda < g.K || g.ldw < g.K || !(g.epi == EPI_VT || g.epi == EPI_RESID)) return false;
     } else if (g.a_k > 0 && (g.a_k % 128 || (g.K != 2 * g.a_k && g.K != 3 * g.a_k))) return false;
     if (g.lda >= (1 << 22) || g.ldw >= (1 << 22)) return false;      // 32-bit operand offsets INSIDE a 256-row tile (tile bases are 64-bit)
+    if (g.n_valid > 0 && g.n_valid != g.N) {   // masked output halves: the last 128 columns of the padded width are dead
+        if (g.n_valid % 128 || g.n_valid > g.N || g.N - g.n_valid != 128 || g.lo8 || g.ksplit > 0 || !(g.epi == EPI_RESID || g.epi == EPI_VT)) return false;
+    }
     if (g.ksplit > 0) {        // split-k: whole PAIRS of k tiles per slice, the last slice included; fp32 partials, no bias, no row map
         const int nt = g.K / 64;
         if (g.epi != EPI_F32 || g.bias || g.lo8 || g.img_rows > 0 || g.ksplit % 2 || g.nslices < 2 || g.nslices > 16 ||

@@ -328,6 +328,275 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
     lbs_pose_person(c, rotvec, betas, expr, loc, dist, Kmat, det_b, P, Pp, F16, A16, xf, j3d, j2d, transl_out, (int)blockIdx.x, L);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the same person as FOUR waves (one per SIMD of a CU).  The one-wave form above executes ~3 100 instructions in a row -- the
+// static 1 725 with the ten-level loop unrolled in time -- and a lone wave issues one VALU instruction per ~5 cycles: 16 k cycles = 8 us
+// of its 10-12 us are ISSUE time, not latency (round 5's review: "2 800 cycles per level").  Here the work is laid across 256 lanes:
+//   phase A  four independent roles, one wave each: Rodrigues + pose feature | joint regression | root rotation, K^-1, translation, feature
+//            tail, zero columns | topology: depth of every joint, the joints of every tree level as a list (ballot + rank)
+//   phase B  the kinematic chain level by level with one lane per (joint of the level, one of its 12 transform elements): a level is
+//            ~10 LDS reads, 3-4 FMAs and one store per lane instead of 21 reads, 36 FMAs and 12 stores
+//   phase C  recentring (one lane), then three roles: folded skinning rows | posed joints + projection | the person record
+//   phase D  the operand rows leave as 16-byte chunks: 160 chunks over 256 lanes, one pass
+// Every expression is the one of lbs_pose_person (same operand order, same contraction), so the results are bit-identical to it
+// (tests/test_gpu_kernels.py::test_lbs_fused_launch_is_bit_identical... compares against the fused launch, which keeps the one-wave form).
+constexpr int POSE_MAXLEVEL = 56;          // a tree of NJ = 55 joints has at most 55 levels: every topology fits
+struct __attribute__((aligned(16))) Pose4Lds {
+    PoseLds L;
+    int sDepth[64];
+    int sCnt[POSE_MAXLEVEL];
+    unsigned char sList[POSE_MAXLEVEL][64];
+    int sMaxDepth;
+};
+
+__global__ __launch_bounds__(256) void lbs_pose4_kernel(const mhmr_lbs_consts c, const float* __restrict__ rotvec,
+                                                       const float* __restrict__ betas, const float* __restrict__ expr,
+                                                       const float* __restrict__ loc, const float* __restrict__ dist,
+                                                       const float* __restrict__ Kmat, const int* __restrict__ det_b, int P, int Pp,
+                                                       _Float16* __restrict__ F16, _Float16* __restrict__ A16, float* __restrict__ xf,
+                                                       float* __restrict__ j3d, float* __restrict__ j2d, float* __restrict__ transl_out) {
+    __shared__ Pose4Lds S;
+    PoseLds& L = S.L;
+    float (&sR)[NJ][9] = L.sR; float (&sJ)[NJ][3] = L.sJ; float (&sRw)[NJ][9] = L.sRw; float (&sTw)[NJ][3] = L.sTw; float (&sX)[36] = L.sX;
+    int (&sPar)[56] = L.sPar;
+    float (&sF)[LBS_KB_POSE] = L.sF; float (&sA)[12][64] = L.sA;
+    const int p = (int)blockIdx.x, tid = threadIdx.x, j = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ngr = Pp / 16, grp = p >> 4, pin = p & 15, nst = c.Kb / 32;
+    typedef Op<MHMR_DT_F16>::V8 H8;
+    // phase D (also the padding rows of both operand matrices: zero = true)
+    auto flush = [&](bool zero) {
+        const int nf = c.Kb / 8;
+        for (int t = tid; t < nf + 96; t += 256) {
+            H8 h, l;
+            if (t < nf) {
+                const int kb = t;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = zero ? 0.f : sF[8 * kb + e];
+                    h[e] = (_Float16)v;
+                    l[e] = (_Float16)(v - (float)h[e]);
+                }
+                _Float16* f = F16 + ((((size_t)grp * 2) * nst + (kb >> 2)) * 64 + (kb & 3) * 16 + pin) * 8;
+                *(H8*)f = h;
+                *(H8*)(f + (size_t)nst * 512) = l;
+            } else {
+                const int ch = t - nf, comp = ch >> 3, jb = ch & 7;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = zero ? 0.f : sA[comp][8 * jb + e];
+                    h[e] = (_Float16)v;
+                    l[e] = (_Float16)(v - (float)h[e]);
+                }
+                _Float16* a = A16 + (((((size_t)comp * 2) * ngr + grp) * 2 + (jb >> 2)) * 64 + (jb & 3) * 16 + pin) * 8;
+                *(H8*)a = h;
+                *(H8*)(a + (size_t)ngr * 1024) = l;
+            }
+        }
+    };
+    if (p >= P) {
+        flush(true);
+        return;
+    }
+    const int ncoef = c.nb + 10;
+    // ---------------- phase A: four roles ----------------
+    if (w == 0) {
+        if (j < NJ) {
+            // full_pose (55) from the reference's 53-vector (smpl_layer.py:88-101), smplx batch_rodrigues -- as in lbs_pose_person
+            int src = -1;
+            if (j >= 1 && j <= 21) src = j;
+            else if (j == 22) src = 52;
+            else if (j >= 25) src = j - 3;
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+            if (src >= 0) {
+                const float* rv = rotvec + ((size_t)p * 53 + src) * 3;
+                v0 = rv[0]; v1 = rv[1]; v2 = rv[2];
+            }
+            const float a0 = v0 + 1e-8f, a1 = v1 + 1e-8f, a2 = v2 + 1e-8f;
+            const float angle = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+            const float rx = v0 / angle, ry = v1 / angle, rz = v2 / angle;
+            float sn, cs;
+            sincosf(angle, &sn, &cs);
+            const float omc = 1.f - cs;
+            const float Km[9] = {0.f, -rz, ry, rz, 0.f, -rx, -ry, rx, 0.f};
+            float KK[9];
+            mat3_mul(Km, Km, KK);
+#pragma unroll
+            for (int e = 0; e < 9; ++e) {
+                const float id = (e == 0 || e == 4 || e == 8) ? 1.f : 0.f;
+                const float r = id + sn * Km[e] + omc * KK[e];
+                sR[j][e] = r;
+                if (j >= 1) sF[(j - 1) * 9 + e] = r - id;
+            }
+        }
+    } else if (w == 1) {
+        if (j < NJ) {
+            if (ncoef == 20) {
+                const f32x4* js = (const f32x4*)(c.JS + (size_t)(j * 3) * 20);
+                f32x4 row[15];
+#pragma unroll
+                for (int i = 0; i < 15; ++i) row[i] = js[i];
+                float cf[20];
+#pragma unroll
+                for (int l = 0; l < 10; ++l) { cf[l] = betas[(size_t)p * 10 + l]; cf[10 + l] = expr[(size_t)p * 10 + l]; }
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    float sm = c.J0[j * 3 + a];
+#pragma unroll
+                    for (int l = 0; l < 20; ++l) sm += row[5 * a + (l >> 2)][l & 3] * cf[l];
+                    sJ[j][a] = sm;
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    float sm = c.J0[j * 3 + a];
+                    const float* js = c.JS + (size_t)(j * 3 + a) * ncoef;
+                    for (int l = 0; l < c.nb; ++l) sm += js[l] * betas[(size_t)p * c.nb + l];
+                    for (int l = 0; l < 10; ++l) sm += js[c.nb + l] * expr[(size_t)p * 10 + l];
+                    sJ[j][a] = sm;
+                }
+            }
+        }
+    } else if (w == 2) {
+        if (j == 63) {
+            // root orientation (roma.rotvec_to_rotmat), translation (inverse_perspective_projection) -- as in lbs_pose_person
+            const float* rv = rotvec + (size_t)p * 53 * 3;
+            const float th = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+            const float den = fmaxf(th, 1e-6f);
+            const float kx = rv[0] / den, ky = rv[1] / den, kz = rv[2] / den;
+            float sn, cs;
+            sincosf(th, &sn, &cs);
+            const float omc = 1.f - cs;
+            const float xs = kx * sn, ys = ky * sn, zs = kz * sn;
+            const float xyc = kx * ky * omc, xzc = kx * kz * omc, yzc = ky * kz * omc;
+            const float xxc = kx * kx * omc, yyc = ky * ky * omc, zzc = kz * kz * omc;
+            const float R0[9] = {1.f - yyc - zzc, xyc - zs, xzc + ys, xyc + zs, 1.f - xxc - zzc, -xs + yzc, xzc - ys, xs + yzc, 1.f - xxc - yyc};
+            const float* Kp = Kmat + (size_t)det_b[p] * 9;
+            float Ki[9];
+            inv3x3(Kp, Ki);
+            const float lx = loc[2 * p], ly = loc[2 * p + 1], d = dist[p];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float tr = (Ki[a * 3] * lx + Ki[a * 3 + 1] * ly + Ki[a * 3 + 2] * 1.0f) * d;
+                sX[24 + a] = tr;
+                transl_out[3 * p + a] = tr;
+            }
+#pragma unroll
+            for (int e = 0; e < 9; ++e) { sX[e] = R0[e]; sX[15 + e] = Kp[e]; }
+        }
+        // feature tail: [betas | expr | 0...]; joints 55..63: zero columns of the skinning operand
+        for (int k = 486 + j; k < c.Kb; k += 64) {
+            const int t = k - 486;
+            float v = 0.f;
+            if (t < c.nb) v = betas[(size_t)p * c.nb + t];
+            else if (t < ncoef) v = expr[(size_t)p * 10 + (t - c.nb)];
+            sF[k] = v;
+        }
+        if (j >= NJ && j < 63) {
+            for (int comp = 0; comp < 12; ++comp) sA[comp][j] = 0.f;
+        }
+        if (j == 63) {
+            for (int comp = 0; comp < 12; ++comp) sA[comp][63] = 0.f;
+        }
+    } else {
+        // topology: parents, depth of every joint, and per tree level the list of its joints (in joint order)
+        if (j < NJ) sPar[j] = c.parents[j];
+        LBS_WAVE_SYNC();
+        int depth = -1;
+        if (j < NJ) {
+            depth = 0;
+            for (int a = sPar[j]; a >= 0; a = sPar[a]) ++depth;
+        }
+        int maxdepth = depth;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) maxdepth = max(maxdepth, __shfl_xor(maxdepth, o));
+        const unsigned long long lt = (1ull << j) - 1ull;
+        for (int level = 0; level <= maxdepth; ++level) {
+            const unsigned long long m = __ballot(depth == level);
+            if (depth == level) S.sList[level][__popcll(m & lt)] = (unsigned char)j;
+            if (j == 0) S.sCnt[level] = __popcll(m);
+        }
+        if (j == 0) S.sMaxDepth = maxdepth;
+    }
+    __syncthreads();
+    // ---------------- phase B: the kinematic chain, one tree level at a time, one lane per (joint, element) ----------------
+    const int maxdepth = S.sMaxDepth;
+    for (int level = 0; level <= maxdepth; ++level) {
+        const int n12 = S.sCnt[level] * 12;
+        for (int t = tid; t < n12; t += 256) {
+            const int slot = t / 12, e = t - slot * 12;
+            const int jj = S.sList[level][slot];
+            const int pa = sPar[jj];
+            if (pa < 0) {                               // a root: its own rotation, its rest position
+                if (e < 9) sRw[jj][e] = sR[jj][e];
+                else sTw[jj][e - 9] = sJ[jj][e - 9];
+            } else if (e < 9) {
+                const int i = e / 3, k = e - i * 3;
+                const float* a = &sRw[pa][0];
+                const float* b = &sR[jj][0];
+                sRw[jj][e] = a[i * 3] * b[k] + a[i * 3 + 1] * b[3 + k] + a[i * 3 + 2] * b[6 + k];
+            } else {
+                const int i = e - 9;
+                const float* a = &sRw[pa][0];
+                const float rel[3] = {sJ[jj][0] - sJ[pa][0], sJ[jj][1] - sJ[pa][1], sJ[jj][2] - sJ[pa][2]};
+                const float tv = a[i * 3] * rel[0] + a[i * 3 + 1] * rel[1] + a[i * 3 + 2] * rel[2];
+                sTw[jj][i] = tv + sTw[pa][i];
+            }
+        }
+        __syncthreads();
+    }
+    // ---------------- phase C: recentring, then the per-joint read-outs ----------------
+    if (tid == 0) {
+        float R0[9], cc[3];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) R0[e] = sX[e];
+        if (c.center_joint >= 0) {
+            float hc[3] = {sTw[c.center_joint][0] - sTw[0][0], sTw[c.center_joint][1] - sTw[0][1], sTw[c.center_joint][2] - sTw[0][2]};
+            mat3_vec(R0, hc, cc);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) cc[a] = -sTw[0][a];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { sX[9 + a] = sTw[0][a]; sX[12 + a] = sX[24 + a] - cc[a]; }
+    }
+    __syncthreads();
+    if (w == 2 && j < 24) xf[(size_t)p * 24 + j] = sX[j];
+    if (w == 0 && j < NJ) {
+        float R0[9], Rw[9], Rf[9], tp[3], tt[3], u[3];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) { R0[e] = sX[e]; Rw[e] = sRw[j][e]; }
+        const float pel[3] = {sX[9], sX[10], sX[11]};
+        float Jv[3] = {sJ[j][0], sJ[j][1], sJ[j][2]};
+        mat3_vec(Rw, Jv, u);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) tp[a] = sTw[j][a] - u[a] - pel[a];
+        mat3_mul(R0, Rw, Rf);
+        mat3_vec(R0, tp, tt);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            sA[r * 4 + 0][j] = Rf[r * 3]; sA[r * 4 + 1][j] = Rf[r * 3 + 1]; sA[r * 4 + 2][j] = Rf[r * 3 + 2];
+            sA[r * 4 + 3][j] = tt[r];
+        }
+    }
+    if (w == 1 && j < NJ) {
+        float R0[9], jj[3];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) R0[e] = sX[e];
+        const float pel[3] = {sX[9], sX[10], sX[11]}, o[3] = {sX[12], sX[13], sX[14]};
+        float dj[3] = {sTw[j][0] - pel[0], sTw[j][1] - pel[1], sTw[j][2] - pel[2]};
+        mat3_vec(R0, dj, jj);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { jj[a] += o[a]; j3d[((size_t)p * 127 + j) * 3 + a] = jj[a]; }
+        float pr[2];
+        project(&sX[15], jj, pr);
+        j2d[((size_t)p * 127 + j) * 2] = pr[0];
+        j2d[((size_t)p * 127 + j) * 2 + 1] = pr[1];
+    }
+    __syncthreads();
+    flush(false);
+}
+
 #ifdef MHMR_LBS_STAMPS      // tools/lbs_timeline.py: per-workgroup s_memtime stamps of wave 0 (debug build only, never in libmhmr.so)
 __device__ unsigned long long* g_lbs_stamps;
 #define LBS_STAMP(i)                                                                                           \
@@ -796,8 +1065,14 @@ static int lbs_forward_impl(const mhmr_lbs_consts* c, const float* rotvec, const
         MHMR_CHECK_LAUNCH();
         return 0;
     }
-    hipLaunchKernelGGL(lbs_pose_kernel, dim3(Pp), dim3(64), 0, s, *c, rotvec, betas, expr, loc, dist, Kmat, det_b, P, Pp,
-                       (_Float16*)ws_F, (_Float16*)ws_A, ws_xf, j3d, j2d, transl);
+    // four waves per person (round 6); MHMR_LBS_POSE1=1: the one-wave form (A/B measurements; bit-identical results)
+    static const bool pose1 = getenv("MHMR_LBS_POSE1") && atoi(getenv("MHMR_LBS_POSE1")) != 0;
+    if (pose1)
+        hipLaunchKernelGGL(lbs_pose_kernel, dim3(Pp), dim3(64), 0, s, *c, rotvec, betas, expr, loc, dist, Kmat, det_b, P, Pp,
+                           (_Float16*)ws_F, (_Float16*)ws_A, ws_xf, j3d, j2d, transl);
+    else
+        hipLaunchKernelGGL(lbs_pose4_kernel, dim3(Pp), dim3(256), 0, s, *c, rotvec, betas, expr, loc, dist, Kmat, det_b, P, Pp,
+                           (_Float16*)ws_F, (_Float16*)ws_A, ws_xf, j3d, j2d, transl);
     MHMR_CHECK_LAUNCH();
     // one launch covers LBS_NC person groups (160 persons); more persons take further launches over the same tiles
     const int ngroups = Pp / 16;

@@ -61,6 +61,10 @@ struct GemmArgs {
     // Split-k (gemm256 only, EPI_F32, no bias): ksplit > 0 = k tiles (of 64) per slice, nslices slices; slice s writes its fp32 partial
     // product into out + s * M * ldo (ldo == N).  For launches of fewer tiles than half the CUs (mhmr_splitk_plan, capi.hip).
     int ksplit = 0, nslices = 0;
+    // Masked output width (gemm256 only, EPI_RESID / EPI_VT): n_valid > 0 and != N: the real width, N - 128 (N = roundup(n_valid, 256));
+    // W and every per-column array (bias, gamma, colsum, fbias) must be readable -- zero-padded -- up to N; `out`, x16 and pstats have the
+    // real width (ldo = n_valid or wider; pstats[row][n_valid / 64][2]); the V^T output has n_valid / 64 heads.
+    int n_valid = 0;
 };
 
 // physical row of logical activation row m (see GemmArgs::img_rows)

@@ -22,6 +22,13 @@ PATCH = 14
 DEFAULT_WLO = "v+proj@0-11"
 
 
+def default_wlo(embed_dim: int) -> str:
+    """The default low-half set by backbone width.  ViT-B / ViT-L: ``DEFAULT_WLO``.  ViT-S (12 blocks of width 384): none -- its goldens sit
+    at <= 4.4e-4 with or without the low halves (profiles/r03_wlo_study_gpu.txt: vits_672_full 3.9e-4 without, 4.4e-4 with), so the second
+    k range of V and proj in all twelve blocks bought nothing there and cost a sixth of the model's GEMM work (round 6)."""
+    return DEFAULT_WLO if embed_dim > 384 else ""
+
+
 def parse_wlo(spec: str, depth: int) -> dict:
     """'v+proj@0-11,proj@12-15' -> {block index: {'v', 'proj'}}; block ranges are clipped to the encoder's depth."""
     out = {}
@@ -129,8 +136,11 @@ def fold_eligible(C: int, N: int) -> bool:
     of an image padded to a multiple of 256 so that the GEMMs cover whole tiles of ALL rows (padded_tokens).  MHMR_LNFOLD=0 /
     MHMR_ROWMAP=0 switch it off (A/B measurements)."""
     import os
+    wide = C % 256 == 0
+    # ViT-S (C = 384, round 6): its C-wide linears run as N = 512 with masked columns (mhmr_vit_desc.cpad), always over all rows
+    narrow = C % 128 == 0 and os.environ.get("MHMR_VITS_256", "1") != "0" and os.environ.get("MHMR_LNFOLD_ALLROWS", "1") != "0"
     return (os.environ.get("MHMR_LNFOLD", "1") != "0" and os.environ.get("MHMR_ROWMAP", "1") != "0" and "MHMR_GEMM128" not in os.environ and
-            C % 256 == 0 and (N % 256 == 0 or os.environ.get("MHMR_LNFOLD_ALLROWS", "1") != "0"))
+            ((wide and (N % 256 == 0 or os.environ.get("MHMR_LNFOLD_ALLROWS", "1") != "0")) or (not wide and narrow)))
 
 
 def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = None, lnfold: bool | None = None) -> dict:
@@ -191,15 +201,26 @@ def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = N
                         norm_b=k(f32(enc.norm.bias)))
         P["keep"] = keep
         return P
-    lo_passes = parse_wlo(DEFAULT_WLO if wlo is None else wlo, L)
+    lo_passes = parse_wlo(default_wlo(Cd) if wlo is None else wlo, L)
     P["wlo"] = {i: sorted(v) for i, v in lo_passes.items()}
     # LayerNorm fold: norm2 -> fc1 in every block, norm1 -> qkv from block 1 on (block 0's norm1 follows the patch embedding, whose
     # epilogue leaves no row statistics: it stays a LayerNorm pass).  A folded linear consumes the RAW 16-bit residual rows:
     #   y = rstd (x16 . W'^T - mean colsum) + b',   W' = W diag(w_ln) (rounded to 16 bits AFTER the fold),  b' = b + W b_ln,
     #   colsum[n] = sum_k W'[n][k] over exactly the 16-bit values the matrix pipe multiplies (hi + lo where there is a low half)
     P["fold"] = fold_eligible(Cd, N) if lnfold is None else bool(lnfold)
-    if P["fold"] and Cd % 256:
-        raise ValueError("lnfold needs embed_dim to be a multiple of 256")
+    if P["fold"] and Cd % 128:
+        raise ValueError("lnfold needs embed_dim to be a multiple of 128")
+    # C = 384 with the fold: every array indexed by the output channel of the C-wide linears (V, proj, fc2) is zero-padded to Cp = 512 rows /
+    # entries -- they run as N = 512 on the 256x256 kernel with the last 128 columns masked (include/mhmr.h, mhmr_vit_desc.cpad)
+    Cp = roundup(Cd, 256)
+    P["cpad"] = Cp if (P["fold"] and Cd % 256) else 0
+
+    def padn(t, n=None):
+        """zero-pad dim 0 to n (default Cp) entries when this pack runs the masked form"""
+        n = Cp if n is None else n
+        if not P["cpad"] or t.shape[0] >= n:
+            return t.contiguous()
+        return torch.cat([t, t.new_zeros((n - t.shape[0],) + tuple(t.shape[1:]))], 0).contiguous()
 
     P["lo8"] = lo8_eligible(Cd) and bool(lo_passes)
 
@@ -227,7 +248,7 @@ def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = N
         f1, f2 = P["fold"] and i > 0, P["fold"]            # block 0's norm1 reads the patch embedding: no producer to fold into
         v_rows = slice(2 * Cd, 3 * Cd)
         blk.flags = (1 if f1 else 0) | (2 if f2 else 0)
-        blk.proj_w2 = k(hi_lo(f32(b.attn.proj.weight), tdt)) if "proj" in lo_passes.get(i, ()) else None
+        blk.proj_w2 = k(padn(hi_lo(f32(b.attn.proj.weight), tdt))) if "proj" in lo_passes.get(i, ()) else None
         blk.v_w8, blk.proj_w8, blk.v_w8_scale, blk.proj_w8_scale = None, None, 127, 127
         if P["lo8"] and "proj" in lo_passes.get(i, ()):
             pw32 = f32(b.attn.proj.weight)
@@ -236,25 +257,25 @@ def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = N
         blk.ln1_w, blk.ln1_b = k(f32(b.norm1.weight)), k(f32(b.norm1.bias))
         if f1:
             w16, bias, colsum, v2, v8 = folded(b.attn.qkv, b.norm1, v_rows if "v" in lo_passes.get(i, ()) else None)
-            blk.qkv_w, blk.qkv_b, blk.qkv_colsum = k(w16), k(bias), k(colsum)
-            blk.v_w2 = k(v2) if v2 is not None else None
+            blk.qkv_w, blk.qkv_b, blk.qkv_colsum = k(padn(w16, 2 * Cd + Cp)), k(padn(bias, 2 * Cd + Cp)), k(padn(colsum, 2 * Cd + Cp))
+            blk.v_w2 = k(padn(v2)) if v2 is not None else None
             if v8 is not None:
                 blk.v_w8, blk.v_w8_scale = k(v8[0]), v8[1]
         else:
-            blk.qkv_w, blk.qkv_b, blk.qkv_colsum = k(op(b.attn.qkv.weight)), k(f32(b.attn.qkv.bias)), None
-            blk.v_w2 = k(hi_lo(f32(b.attn.qkv.weight)[v_rows], tdt)) if "v" in lo_passes.get(i, ()) else None
+            blk.qkv_w, blk.qkv_b, blk.qkv_colsum = k(padn(op(b.attn.qkv.weight), 2 * Cd + Cp)), k(padn(f32(b.attn.qkv.bias), 2 * Cd + Cp)), None
+            blk.v_w2 = k(padn(hi_lo(f32(b.attn.qkv.weight)[v_rows], tdt))) if "v" in lo_passes.get(i, ()) else None
             if P["lo8"] and "v" in lo_passes.get(i, ()):
                 vw32 = f32(b.attn.qkv.weight)[v_rows]
                 rows8, blk.v_w8_scale, _ = lo8_rows(vw32.to(tdt), vw32)
                 blk.v_w8 = k(rows8)
-        blk.proj_w, blk.proj_b, blk.ls1 = k(op(b.attn.proj.weight)), k(f32(b.attn.proj.bias)), k(f32(b.ls1.gamma))
+        blk.proj_w, blk.proj_b, blk.ls1 = k(padn(op(b.attn.proj.weight))), k(padn(f32(b.attn.proj.bias))), k(padn(f32(b.ls1.gamma)))
         blk.ln2_w, blk.ln2_b = k(f32(b.norm2.weight)), k(f32(b.norm2.bias))
         if f2:
             w16, bias, colsum, _, _ = folded(b.mlp.fc1, b.norm2)
             blk.fc1_w, blk.fc1_b, blk.fc1_colsum = k(w16), k(bias), k(colsum)
         else:
             blk.fc1_w, blk.fc1_b, blk.fc1_colsum = k(op(b.mlp.fc1.weight)), k(f32(b.mlp.fc1.bias)), None
-        blk.fc2_w, blk.fc2_b, blk.ls2 = k(op(b.mlp.fc2.weight)), k(f32(b.mlp.fc2.bias)), k(f32(b.ls2.gamma))
+        blk.fc2_w, blk.fc2_b, blk.ls2 = k(padn(op(b.mlp.fc2.weight))), k(padn(f32(b.mlp.fc2.bias))), k(padn(f32(b.ls2.gamma)))
     P["vit"] = dict(blocks=blocks, patch_w=k(pw.to(tdt).contiguous()), patch_b=k(f32(enc.patch_embed.proj.bias)),
                     cls_pos0=k(cls_pos0.contiguous()), pos=k(pos.contiguous()), norm_w=k(f32(enc.norm.weight)),
                     norm_b=k(f32(enc.norm.bias)))
@@ -288,8 +309,8 @@ def padded_tokens(P: dict, B: int) -> int:
     import os
     if P.get("x3"):
         return roundup(P["T"], 256 if P["C"] % 256 == 0 else 128)      # all rows through every linear: whole tiles for every batch size
-    if P.get("fold") and ((P["T"] - 1) % 256 or (not row_map(P, B) and tiny_batch(P, B) and os.environ.get("MHMR_ROWMAP", "1") != "0" and
-                                              "MHMR_GEMM128" not in os.environ)):
+    if P.get("fold") and (P.get("cpad") or (P["T"] - 1) % 256 or (not row_map(P, B) and tiny_batch(P, B) and os.environ.get("MHMR_ROWMAP", "1") != "0" and
+                                                                  "MHMR_GEMM128" not in os.environ)):
         return roundup(P["T"], 256)        # folded LayerNorms without the row map: whole 256-row tiles of all rows, for every batch size
     t64, t128 = roundup(P["T"], 64), roundup(P["T"], 128)
     # the predicate of csrc/gemm256.hip mhmr_gemm256_eligible for the residual GEMMs over all B * Tp rows (32-bit residual offsets),
@@ -366,6 +387,7 @@ class WorkspaceCache:
             d.pstats = b["pstats"].data_ptr() if P.get("fold") else None
             d.rowstats = b["rowstats"].data_ptr() if P.get("fold") else None
             d.splitk, d.splitk_bytes = (b["splitk"].data_ptr(), skb) if skb else (None, 0)
+            d.cpad = P.get("cpad", 0) if not x3 else 0
             parts.append(dict(desc=d, B=Bh, img0=i * Bh, bufs=b))
         ws = dict(parts[0]["bufs"])
         ws["feat32"] = z(B * N, Cd, dtype=torch.float32)

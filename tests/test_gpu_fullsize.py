@@ -38,10 +38,16 @@ def test_vitl_896_batch_invariance_and_determinism(model_896, monkeypatch):
     # kernel -- another fp32 summation order for that one row, which every token attends to, and in a 16-bit pipeline a 1e-6 perturbation
     # flips roundings downstream: image 1 alone then agrees with image 1 inside the batch to the 16-bit noise level (measured 1.3e-4 on
     # v3d in the max norm), not to the last bit ...
+    # Round 6: the residual linears of a batch of one are split over k (csrc/gemm256.hip SPLITK), so EVERY token row takes another summation
+    # order than inside a batch; two valid roundings of a 16-bit pipeline differ by about what either differs from the fp32 reference
+    # (measured 6.3e-4 on rotmat in the max norm): the bounds are the parity contract's own -- 5e-4 in relative L2 (half of parity.TOL, i.e.
+    # both runs cannot sit on opposite sides of the reference), parity.MAXTOL in the max norm.
+    import parity
     c = model_896(x[1:2], idx=idx1, K=K[1:2], is_training=True)
     for k, ref in a_sel.items():
         d = (c[k] - ref).abs().max() / ref.abs().max()
-        assert float(d) < 5e-4, (k, float(d))
+        l2 = (c[k] - ref).norm() / ref.norm()
+        assert float(d) < parity.MAXTOL["f16"] and float(l2) < 5e-4, (k, float(d), float(l2))
     # ... and with the SAME row mode (token-row map + class-row kernel, what every larger batch takes) it is the same arithmetic in the
     # same order: image 1 alone == image 1 inside the batch
     monkeypatch.setenv("MHMR_TINY_ALLROWS", "0")

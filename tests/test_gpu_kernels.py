@@ -895,3 +895,58 @@ def test_splitk_plan_declines_long_launches(L):
     assert L.mhmr_splitk_workspace_bytes(256 * 129, 1024, 4096) == 0      # 516 tiles
     assert L.mhmr_splitk_workspace_bytes(4352, 1024, 256) == 0             # four k tiles
     assert L.mhmr_splitk_workspace_bytes(4352 + 128, 1024, 4096) == 0      # M not a multiple of 256
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("K,a_k", [(384, 0), (1536, 0), (768, 384)])
+def test_gemm_masked_output_width(L, name, dt, tdt, tol, K, a_k):
+    """mhmr_gemm16_masked: an output width of 384 (ViT-S) on the 256x256 kernel as N = 512 with zero-padded weight rows / per-column vectors
+    and the last 128 columns masked -- the residual epilogue (with the LayerNorm-fold producer outputs at the real width) and the V^T
+    epilogue (plain and as a fold consumer) against fp64 torch; nothing may be written behind column 384 / head 6."""
+    M, Nv, Np, Tp = 512, 384, 512, 256
+    B, H = M // Tp, Nv // 64
+    ka = a_k if a_k else K
+    g = torch.Generator(device=dev()).manual_seed(K + a_k)
+    A = torch.randn(M, ka, generator=g, device=dev()).to(tdt)
+    Aw = torch.cat([A, A], 1) if a_k else A
+
+    def padded(t):
+        return torch.cat([t, torch.zeros(Np - Nv, *t.shape[1:], dtype=t.dtype, device=t.device)], 0).contiguous()
+
+    W = (torch.randn(Nv, K, generator=g, device=dev()) / math.sqrt(ka)).to(tdt)
+    bias, gamma = torch.randn(Nv, generator=g, device=dev()), 0.5 + torch.rand(Nv, generator=g, device=dev())
+    Wp, bp, gp = padded(W), padded(bias), padded(gamma)
+    # ---- residual epilogue + fold producer ----
+    r0 = torch.randn(M + 1, Nv, generator=g, device=dev())             # one guard row behind the matrix
+    r = r0.clone()
+    x16 = torch.full((M + 1, Nv), 7.0, dtype=tdt, device=dev())
+    pst = torch.full((M + 1, Nv // 64, 2), -1.0, device=dev())
+    _lib.check(L.mhmr_gemm16_masked(A.data_ptr(), ka, Wp.data_ptr(), K, M, Np, Nv, K, a_k, bp.data_ptr(), gp.data_ptr(), r.data_ptr(), Nv, Tp, H,
+                                    _lib.EPI_RESID, dt, x16.data_ptr(), pst.data_ptr(), None, None, None, stream()), "masked resid")
+    ref = r0[:M].double() + gamma.double() * (Aw.double() @ W.double().T + bias.double())
+    assert maxrel(r[:M], ref) < 2e-5 and torch.equal(r[M], r0[M])
+    assert torch.equal(x16[:M], r[:M].to(tdt)) and torch.all(x16[M] == 7.0)
+    blocks = r[:M].view(M, Nv // 64, 64)
+    assert maxrel(pst[:M, :, 0], blocks.sum(-1)) < 1e-5 and maxrel(pst[:M, :, 1], (blocks * blocks).sum(-1)) < 1e-5 and torch.all(pst[M] == -1.0)
+    # ---- V^T epilogue: plain, and as the consumer of a folded LayerNorm ----
+    perm = swap23(torch.arange(Tp, device=dev()))
+    for fold in (False, True):
+        vt = torch.full((B * H + 1, 64, Tp), 7.0, dtype=tdt, device=dev())          # one guard head
+        if fold:
+            rs = torch.stack([torch.randn(M, generator=g, device=dev()) * 0.3, 0.5 + torch.rand(M, generator=g, device=dev())], 1).contiguous()
+            colsum = padded(W.double().sum(1).float())
+            _lib.check(L.mhmr_gemm16_masked(A.data_ptr(), ka, Wp.data_ptr(), K, M, Np, Nv, K, a_k, None, None, vt.data_ptr(), 0, Tp, H, _lib.EPI_VT, dt,
+                                            None, None, rs.data_ptr(), colsum.data_ptr(), bp.data_ptr(), stream()), "masked vt fold")
+            want = rs[:, 1:2].double() * (Aw.double() @ W.double().T - rs[:, 0:1].double() * W.double().sum(1)) + bias.double()
+        else:
+            if K < 256:
+                continue
+            _lib.check(L.mhmr_gemm16_masked(A.data_ptr(), ka, Wp.data_ptr(), K, M, Np, Nv, K, a_k, bp.data_ptr(), None, vt.data_ptr(), 0, Tp, H, _lib.EPI_VT, dt,
+                                            None, None, None, None, None, stream()), "masked vt")
+            want = Aw.double() @ W.double().T + bias.double()
+        got = vt[: B * H].float().view(B, H, 64, Tp)[..., perm].permute(0, 3, 1, 2).reshape(M, Nv)
+        assert maxrel(got, want) < tol, (fold, maxrel(got, want))
+        assert torch.all(vt[B * H] == 7.0)
+    # the unmasked kernels refuse a width that is not a multiple of 256; the masked form refuses anything but N = n_valid + 128
+    assert L.mhmr_gemm16_masked(A.data_ptr(), ka, Wp.data_ptr(), K, M, Np, 256, K, a_k, bp.data_ptr(), gp.data_ptr(), r.data_ptr(), Nv, Tp, H,
+                                _lib.EPI_RESID, dt, None, None, None, None, None, stream()) != 0

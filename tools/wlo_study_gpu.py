@@ -37,7 +37,7 @@ def main():
         model.load_state_dict(make_golden.case_state_dict(cfg), strict=True)
         model = model.to("cuda:0").eval()
         for spec in a.specs.split(","):
-            model.wlo = "" if spec == "none" else spec
+            model.wlo = "" if spec == "none" else spec.replace("|", ",")        # ("a|b" on the command line = the two-part spec "a,b")
             model.repack()
             z = model.backbone_features(x.cuda()).cpu()
             out = model(x.cuda(), idx=tuple(i.cuda() for i in idx), K=K.cuda(), is_training=True)
