@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define MHMR_VERSION 105   /* 105: mhmr_vit_desc.cpad (ViT-S on the 256x256 kernel: C-wide linears as N = 512 with masked columns); mhmr_vit_desc.{splitk, splitk_bytes}, mhmr_splitk_workspace_bytes, mhmr_gemm16_splitk_resid: split-k residual linears for launches that fill less than half the chip (a batch of one); 104: mhmr_vit_desc.{x3, qkv32, hid32}: the f16x3 precision mode (three 16-bit products per term in every backbone linear, fp32 attention); mhmr_gemm16_ex a_k with K = 3 a_k; mhmr_attention_f32; 103: mhmr_attention16_ex variant 6 (the default of mhmr_vit_forward); mhmr_camera_embed(num_bands), mhmr_hph_desc.cam_dim; mhmr_lbs_consts.basis16 layout (high halves for k < Kb - 64); mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
+#define MHMR_VERSION 105   /* 105: mhmr_vit_desc.v16 (merged qkv launch of a short batch); mhmr_vit_desc.cpad (ViT-S on the 256x256 kernel: C-wide linears as N = 512 with masked columns); mhmr_vit_desc.{splitk, splitk_bytes}, mhmr_splitk_workspace_bytes, mhmr_gemm16_splitk_resid: split-k residual linears for launches that fill less than half the chip (a batch of one); 104: mhmr_vit_desc.{x3, qkv32, hid32}: the f16x3 precision mode (three 16-bit products per term in every backbone linear, fp32 attention); mhmr_gemm16_ex a_k with K = 3 a_k; mhmr_attention_f32; 103: mhmr_attention16_ex variant 6 (the default of mhmr_vit_forward); mhmr_camera_embed(num_bands), mhmr_hph_desc.cam_dim; mhmr_lbs_consts.basis16 layout (high halves for k < Kb - 64); mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
 
 #define MHMR_OK 0
 #define MHMR_ERR_BAD_ARG (-1)
@@ -141,6 +141,10 @@ typedef struct {
      * ls2 [512].  Those linears then run as N = 512 with the last 128 output columns masked (GemmArgs::n_valid), every block linear is
      * on the 256x256 kernel and the LayerNorm fold applies.  0 = C-wide linears of such a model run on the 128x128 kernel, no fold. */
     int cpad;
+    /* op16 [B*Tp, C] or NULL.  Given (with Tp % 256 == 0, all rows through the 256x256 kernel) and the whole qkv linear at most one round
+     * of 256x256 tiles (B*Tp/256 * 3C/256 <= CUs): blocks whose V has no low half run Q | K | V as ONE launch -- V row-major into this
+     * buffer -- followed by a transpose into `vt`, instead of a Q | K and a V launch of half a round each. */
+    void* v16;
 } mhmr_vit_desc;
 
 /* x: [B,3,S,S] fp32 (ImageNet-normalised).  feat32: [B*N, C] fp32 patch features (token n = y*G + x).
@@ -173,6 +177,11 @@ int mhmr_gemm16_ln(const void* A, int lda, const void* W, int ldw, int M, int N,
 int mhmr_gemm16_masked(const void* A, int lda, const void* W, int ldw, int M, int N, int n_valid, int K, int a_k, const float* bias,
                        const float* gamma, void* out, int ldo, int Tp, int H, int epi, int dtype, void* x16, float* pstats,
                        const float* rowstats, const float* colsum, const float* fbias, void* stream);
+/* The qkv linear of a SHORT batch as one launch + a transpose (what mhmr_vit_forward runs when mhmr_vit_desc.v16 is given): W [3C, K = C],
+ * qk [B*Tp, 2C] = (Q * MHMR_ATTN_QSCALE | K), vt [B][H][64][Tp] with the key permutation of MHMR_EPI_VT, v16 [B*Tp, C] scratch.
+ * B*Tp % 256 == 0, C % 256 == 0, Tp % 64 == 0.  rowstats / colsum [3C] / fbias [3C]: the LayerNorm-fold consumer form (then bias = NULL). */
+int mhmr_qkv16(const void* A, int lda, const void* W, int ldw, int B, int Tp, int C, int H, const float* bias, void* qk, void* v16, void* vt,
+               int dtype, const float* rowstats, const float* colsum, const float* fbias, void* stream);
 /* Split-k residual linear (csrc/gemm256.hip SPLITK + csrc/vit_misc.hip splitk_resid_kernel): out32 += gamma * (A . W^T + bias) for a launch
  * that would otherwise occupy at most half of the CUs.  mhmr_splitk_workspace_bytes: bytes of fp32 partial tiles the pair needs for an
  * [M, N] output over K (0 = such a problem is not split: M, N % 256, K % 128, tiles <= CUs / 2, K >= 512).  a_k as in mhmr_gemm16_ex.

@@ -106,7 +106,7 @@ class VitDesc(C.Structure):
                 [("patch_w", _vp), ("patch_b", _vp), ("cls_pos0", _vp), ("pos", _vp), ("blocks", C.POINTER(VitBlock)),
                  ("norm_w", _vp), ("norm_b", _vp)] +
                 [(n, _vp) for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid", "attn_flags", "pstats", "rowstats")] +
-                [("lo8", _i), ("x3", _i), ("qkv32", _vp), ("hid32", _vp), ("splitk", _vp), ("splitk_bytes", C.c_longlong), ("cpad", _i)])
+                [("lo8", _i), ("x3", _i), ("qkv32", _vp), ("hid32", _vp), ("splitk", _vp), ("splitk_bytes", C.c_longlong), ("cpad", _i), ("v16", _vp)])
 
 
 class HphLayer(C.Structure):
@@ -137,6 +137,7 @@ _SIGS = {
     "mhmr_gemm16_ln": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "mhmr_gemm16_lo8": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
     "mhmr_gemm16_masked": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "mhmr_qkv16": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp], _i),
     "mhmr_splitk_workspace_bytes": ([_i, _i, _i], C.c_longlong),
     "mhmr_gemm16_splitk_resid": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, C.c_longlong, _i, _vp], _i),
     "mhmr_ln_stats": ([_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),

@@ -42,6 +42,7 @@ int mhmr_launch_gelu_pair(const float* in, void* out, long long M, int N, int dt
 int mhmr_launch_splitk_resid(const float* part, int nslices, int rows, int C, const float* bias, const float* gamma, float* resid, void* x16,
                              int ldx, float* rowstats, float eps, int dtype, hipStream_t s);
 bool mhmr_splitk_plan(int M, int N, int K, int* ksplit, int* nslices);
+int mhmr_launch_vt_transpose(const void* v, int ldv, void* vt, int B, int Tp, int H, int dtype, hipStream_t s);
 int mhmr_launch_loc(const float* offset, const int* det_y, const int* det_x, int patch, float* loc, int P, hipStream_t s);
 
 thread_local int g_mhmr_anyorder = 0;        // mhmr_internal.h: the next launches of this host thread go out without the AQL barrier bit
@@ -196,6 +197,20 @@ int mhmr_gemm16_masked(const void* A, int lda, const void* W, int ldw, int M, in
     g.fbias = fbias;
     if (n_valid <= 0 || n_valid >= N) return MHMR_ERR_BAD_ARG;
     return mhmr_launch_gemm(g, dtype, (hipStream_t)stream);
+}
+
+// The whole qkv linear of a short batch as ONE launch (gemm256.hip QKV) + the transpose of its V rows: qk [M, 2C] = (Q scaled | K),
+// v16 [M, C] (scratch), vt [B][H][64][Tp] key-permuted; M = B * Tp.  rowstats / colsum / fbias: the LayerNorm-fold consumer form (bias NULL).
+int mhmr_qkv16(const void* A, int lda, const void* W, int ldw, int B, int Tp, int C, int H, const float* bias, void* qk, void* v16, void* vt,
+               int dtype, const float* rowstats, const float* colsum, const float* fbias, void* stream) {
+    if (!A || !W || !qk || !v16 || !vt || B <= 0 || C != 64 * H) return MHMR_ERR_BAD_ARG;
+    const int M = B * Tp;
+    GemmArgs g{A, lda, W, ldw, M, 3 * C, C, bias, nullptr, qk, 2 * C, nullptr, 0, Tp, H, M, EPI_OP16_QK};
+    g.out2 = v16; g.ldo2 = C; g.split_col = 2 * C; g.qcols = C;
+    g.rowstats = rowstats; g.colsum = colsum; g.fbias = fbias;
+    int rc = mhmr_launch_gemm(g, dtype, (hipStream_t)stream);
+    if (rc) return rc;
+    return mhmr_launch_vt_transpose(v16, C, vt, B, Tp, H, dtype, (hipStream_t)stream);
 }
 
 long long mhmr_splitk_workspace_bytes(int M, int N, int K) {
@@ -441,6 +456,15 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
                 g.bias = nullptr; g.rowstats = d->rowstats; g.colsum = k.qkv_colsum; g.fbias = k.qkv_b;
                 gv.bias = nullptr; gv.rowstats = d->rowstats; gv.colsum = k.qkv_colsum + 2 * C; gv.fbias = k.qkv_b + 2 * C;
             }
+            // A short batch (all rows, the whole qkv linear at most one round of tiles): ONE launch for Q | K | V + a transpose of the V rows
+            // (gemm256.hip QKV), instead of two launches of half a round each.  Needs mhmr_vit_desc.v16 and a V without a low half.
+            static const bool qkv_env = !(getenv("MHMR_QKV_MERGE") && atoi(getenv("MHMR_QKV_MERGE")) == 0);
+            if (qkv_env && allrows256 && !nmask && d->v16 && !k.v_w2 && !vlo8 && (M / 256) * (3 * C / 256) <= mhmr_cu_count()) {
+                g.N = 3 * C;
+                g.out2 = d->v16; g.ldo2 = C; g.split_col = 2 * C; g.qcols = C;
+                TRY(mhmr_launch_gemm(g, dt, s));
+                TRY(mhmr_launch_vt_transpose(d->v16, C, d->vt, B, Tp, d->H, dt, s));
+            } else {
             TRY(mhmr_launch_gemm(g, dt, s));
             AnyOrder ao_scope(ao);           // V and the class rows of Q | K | V: beside the Q | K projection
             TRY(mhmr_launch_gemm(gv, dt, s));
@@ -456,6 +480,7 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
                     TRY(mhmr_launch_cls_linear_fold(xr, rowP, v_wc, v_kc, B, C, v_kc, v_akc, f1 ? nullptr : k.qkv_b + 2 * C, nullptr, qr, 2 * rowC, 2 * C, C,
                                                     d->vt, d->H, Tp, vcol, 0, dt, st, 2LL * Tp, f1 ? k.qkv_colsum + 2 * C : nullptr,
                                                     k.qkv_b + 2 * C, nullptr, 0, s));
+            }
             }
         }
         TRY(mhmr_launch_attention(d->qk, d->vt, d->att, B, d->T, Tp, C, d->H, dt, d->attn_flags, s, pit, plo8 ? o8 : 0));

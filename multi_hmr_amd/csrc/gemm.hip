@@ -315,6 +315,7 @@ int mhmr_launch_gemm(const GemmArgs& g, int dtype, hipStream_t s) {
     if (g.lo8 && (g_force_gemm128 || !mhmr_gemm256_eligible(g))) return MHMR_ERR_BAD_SHAPE;      // fp8 low-half range: 256x256 kernel only
     if ((g.x8_off > 0 || g.ldx16 > 0) && !g.x16) return MHMR_ERR_BAD_ARG;
     if (g.ksplit > 0 && (g_force_gemm128 || !mhmr_gemm256_eligible(g))) return MHMR_ERR_BAD_SHAPE;   // split-k: 256x256 kernel only
+    if (g.out2 && (g_force_gemm128 || !mhmr_gemm256_eligible(g))) return MHMR_ERR_BAD_SHAPE;         // merged qkv linear: 256x256 kernel only
     if (g.n_valid > 0 && g.n_valid != g.N && (g_force_gemm128 || !mhmr_gemm256_eligible(g))) return MHMR_ERR_BAD_SHAPE;   // masked output halves likewise
     if (g.x16 || g.pstats || g.rowstats) {       // LayerNorm fold: 256x256 kernel only
         if (g_force_gemm128 || !mhmr_gemm256_eligible(g)) return MHMR_ERR_BAD_SHAPE;

@@ -122,8 +122,13 @@ __device__ int g_gemm_sametile;      // 1: every tile reads the operands of tile
 // N = 512 with the weight rows (and every per-column array: bias, gamma, colsum, fbias) zero-padded by the caller; the 128-column half
 // tiles at or behind n_valid are computed (zeros) and not stored -- 25 % of such a launch's matrix work is padding, at three times the
 // rate the 128x128 kernel reaches on the same shape.
-template <int DT, int EPI, bool FOLD = false, bool LO8 = false, bool SPLITK = false, bool NMASK = false>
+// QKV (GemmArgs::out2; EPI_OP16_QK only): ONE launch for the whole qkv linear of a short batch (N = 3C: Q | K | V).  Column tiles in front of
+// split_col (= 2C) go to `out` (the Q | K rows the attention kernel reads, Q scaled: columns < qcols = C), the others -- V -- row-major to
+// out2 [M, ldo2]; vit_misc.hip's vt_transpose_kernel makes the key-permuted V^T of them.  For a batch of one the Q | K projection (136 of 256
+// CUs at 896^2) and the V projection (68) were two launches of half a round each.
+template <int DT, int EPI, bool FOLD = false, bool LO8 = false, bool SPLITK = false, bool NMASK = false, bool QKV = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
+    static_assert(!QKV || (EPI == EPI_OP16_QK && !LO8 && !SPLITK && !NMASK), "merged qkv linear: the Q | K epilogue");
     static_assert(!SPLITK || (EPI == EPI_F32 && !FOLD && !LO8), "split-k: fp32 partial tiles only");
     static_assert(!NMASK || ((EPI == EPI_RESID || EPI == EPI_VT) && !LO8 && !SPLITK), "masked output halves: residual and V^T epilogues");
     typedef typename Op<DT>::T T;
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                     }
                 }
                 if constexpr (OUT16) {
-                    const float qscale = (EPI == EPI_OP16_QK && pb < (g.N >> 1)) ? MHMR_ATTN_QSCALE : 1.f;   // 64 columns: all Q or all K
+                    const float qscale = (EPI == EPI_OP16_QK && pb < (QKV ? g.qcols : (g.N >> 1))) ? MHMR_ATTN_QSCALE : 1.f;   // 64 columns: all Q or all K
 #pragma unroll
                     for (int qh = 0; qh < NPASS; ++qh) {
                         // Q-side values of this pass's rows (fold): one position per lane and qs
@@ -599,7 +604,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                             const int srow = 8 * it + (lane >> 3), c16 = lane & 7;      // row of the staging image
                             const int row = (FOLDABLE ? 16 * qh : 0) + srow;            // Q row of the (h, j) block
                             const u32x4 v = *(const u32x4*)(wl + srow * 128 + ((c16 ^ (srow & 7)) * 16));
-                            if constexpr (ROWMAJOR) {
+                            if constexpr (ROWMAJOR && QKV) {
+                                const bool second = pb >= g.split_col;          // (wave-uniform: a 64-column block is all Q | K or all V)
+                                T* ob = second ? (T*)g.out2 : (T*)g.out;
+                                const int ld = second ? g.ldo2 : g.ldo, col = second ? pb - g.split_col : pb;
+                                *(u32x4*)(ob + (size_t)(qphys + row) * ld + col + c16 * 8) = v;
+                            } else if constexpr (ROWMAJOR) {
                                 *(u32x4*)((T*)g.out + (size_t)(qphys + row) * g.ldo + pb + c16 * 8) = v;
                             } else {
                                 // image and token-in-image of the block's first (logical) token row
@@ -666,20 +676,21 @@ int launch256_dt(const GemmArgs& g, hipStream_t s) {
     if (ncu <= 0) return MHMR_ERR_BAD_ARG;
     const int grid = ntiles < ncu ? ntiles : ncu;      // one persistent block per CU
     // 160 KiB of dynamic LDS: the attribute is per device (DeviceOnce, mhmr_internal.h)
-#define MHMR_GEMM_LAUNCH10(E, F, L8, SK, NM)                                                                   \
+#define MHMR_GEMM_LAUNCH11(E, F, L8, SK, NM, QV)                                                               \
     {                                                                                                          \
         static DeviceOnce once;                                                                                \
         int dev = 0;                                                                                           \
         const int need = once.need(&dev);                                                                      \
         if (need == -2) return MHMR_ERR_BAD_ARG;                                                               \
         if (need >= 0) {                                                                                       \
-            hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DT, E, F, L8, SK, NM>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<DT, E, F, L8, SK, NM, QV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                LDS_BYTES);                                                     \
             if (e != hipSuccess) return (int)e;                                                                \
             once.mark(dev);                                                                                    \
         }                                                                                                      \
-        mhmr_launch_kernel(gemm256_kernel<DT, E, F, L8, SK, NM>, dim3(grid), dim3(512), LDS_BYTES, s, g);      \
+        mhmr_launch_kernel(gemm256_kernel<DT, E, F, L8, SK, NM, QV>, dim3(grid), dim3(512), LDS_BYTES, s, g);  \
     }
+#define MHMR_GEMM_LAUNCH10(E, F, L8, SK, NM) MHMR_GEMM_LAUNCH11(E, F, L8, SK, NM, false)
 #define MHMR_GEMM_LAUNCH9(E, F, L8, SK) MHMR_GEMM_LAUNCH10(E, F, L8, SK, false)
 #define MHMR_GEMM_LAUNCH8(E, F, L8) MHMR_GEMM_LAUNCH9(E, F, L8, false)
 #define MHMR_GEMM_LAUNCH(E, F) MHMR_GEMM_LAUNCH8(E, F, false)
@@ -687,6 +698,13 @@ int launch256_dt(const GemmArgs& g, hipStream_t s) {
     case E: MHMR_GEMM_LAUNCH(E, false) break;
     if (g.ksplit > 0) {                     // split-k: fp32 partial tiles of a short launch (eligibility: mhmr_gemm256_eligible)
         MHMR_GEMM_LAUNCH9(EPI_F32, false, false, true)
+        MHMR_CHECK_LAUNCH();
+        return 0;
+    }
+    if (g.out2) {                                   // merged qkv linear (plain or as the consumer of a folded LayerNorm)
+        if (g.epi != EPI_OP16_QK) return MHMR_ERR_BAD_ARG;
+        if (g.rowstats) MHMR_GEMM_LAUNCH11(EPI_OP16_QK, true, false, false, false, true)
+        else MHMR_GEMM_LAUNCH11(EPI_OP16_QK, false, false, false, false, true)
         MHMR_CHECK_LAUNCH();
         return 0;
     }
@@ -733,6 +751,7 @@ int launch256_dt(const GemmArgs& g, hipStream_t s) {
 #undef MHMR_GEMM_LAUNCH8
 #undef MHMR_GEMM_LAUNCH9
 #undef MHMR_GEMM_LAUNCH10
+#undef MHMR_GEMM_LAUNCH11
     MHMR_CHECK_LAUNCH();
     return 0;
 }
@@ -749,6 +768,11 @@ bool mhmr_gemm256_eligible(const GemmArgs& g) {
     if (g.lda >= (1 << 22) || g.ldw >= (1 << 22)) return false;      // 32-bit operand offsets INSIDE a 256-row tile (tile bases are 64-bit)
     if (g.n_valid > 0 && g.n_valid != g.N) {   // masked output halves: the last 128 columns of the padded width are dead
         if (g.n_valid % 128 || g.n_valid > g.N || g.N - g.n_valid != 128 || g.lo8 || g.ksplit > 0 || !(g.epi == EPI_RESID || g.epi == EPI_VT)) return false;
+    }
+    if (g.out2) {              // merged qkv linear: whole 64-column blocks on either side of split_col, Q columns in front of it
+        if (g.epi != EPI_OP16_QK || g.split_col <= 0 || g.split_col % 64 || g.split_col >= g.N || g.qcols < 0 || g.qcols % 64 || g.qcols > g.split_col ||
+            g.ldo2 < g.N - g.split_col || g.lo8 || g.ksplit > 0 || g.n_valid > 0)
+            return false;
     }
     if (g.ksplit > 0) {        // split-k: whole PAIRS of k tiles per slice, the last slice included; fp32 partials, no bias, no row map
         const int nt = g.K / 64;

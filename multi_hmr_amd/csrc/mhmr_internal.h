@@ -65,6 +65,10 @@ struct GemmArgs {
     // W and every per-column array (bias, gamma, colsum, fbias) must be readable -- zero-padded -- up to N; `out`, x16 and pstats have the
     // real width (ldo = n_valid or wider; pstats[row][n_valid / 64][2]); the V^T output has n_valid / 64 heads.
     int n_valid = 0;
+    // Merged qkv linear (gemm256 only, EPI_OP16_QK): out2 != null: output columns >= split_col go row-major to out2 [M, ldo2] (column
+    // n - split_col), the others to out; the softmax scale applies to columns < qcols.
+    void* out2 = nullptr;
+    int ldo2 = 0, split_col = 0, qcols = 0;
 };
 
 // physical row of logical activation row m (see GemmArgs::img_rows)

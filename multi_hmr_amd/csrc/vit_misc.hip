@@ -227,6 +227,36 @@ __global__ __launch_bounds__(256) void splitk_resid_kernel(const float* __restri
     }
 }
 
+// V rows [B * Tp, ldv] (row-major, head h at columns 64 h) -> the attention kernel's V^T [B][H][64][Tp] with the key permutation of the V^T
+// GEMM epilogue (bits 2 <-> 3 of the token index swapped inside every 16-group).  Behind the merged qkv linear of a short batch (gemm256.hip
+// QKV).  One workgroup = one (64 tokens, head, image) tile through LDS; 16-byte loads and stores.
+template <int DT>
+__global__ __launch_bounds__(256) void vt_transpose_kernel(const void* __restrict__ v_, int ldv, void* __restrict__ vt_, int Tp, int H) {
+    typedef typename Op<DT>::T T;
+    typedef typename Op<DT>::V8 V8;
+    __shared__ T tile[64][72];                 // [token][d], 144-byte rows
+    const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const T* v = (const T*)v_;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i, t = idx >> 3, ch = idx & 7;
+        *(V8*)&tile[t][ch * 8] = *(const V8*)(v + ((size_t)b * Tp + t0 + t) * ldv + h * 64 + ch * 8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i, d = idx >> 3, ch = idx & 7;
+        V8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int tp = ch * 8 + e;                                        // position in the permuted row
+            const int ts = (tp & ~12) | ((tp & 4) << 1) | ((tp & 8) >> 1);    // the token it holds (the swap is its own inverse)
+            o[e] = tile[ts][d];
+        }
+        *(V8*)((T*)vt_ + ((size_t)(b * H + h) * 64 + d) * Tp + t0 + ch * 8) = o;
+    }
+}
+
 // exact-erf GELU of an fp32 matrix [M, N] -> the op16 pair [M, 2 N] = [hi | lo] (the f16x3 mode's fc2 operand); 4 values per thread
 template <int DT>
 __global__ __launch_bounds__(256) void gelu_pair_kernel(const float* __restrict__ in, void* __restrict__ out_, long long total4, int N) {
@@ -308,6 +338,15 @@ int mhmr_launch_gelu_pair(const float* in, void* out, long long M, int N, int dt
     const int grid = (int)((total4 + 255) / 256);
     if (dtype == MHMR_DT_F16) hipLaunchKernelGGL((gelu_pair_kernel<MHMR_DT_F16>), dim3(grid), dim3(256), 0, s, in, out, total4, N);
     else hipLaunchKernelGGL((gelu_pair_kernel<MHMR_DT_BF16>), dim3(grid), dim3(256), 0, s, in, out, total4, N);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
+int mhmr_launch_vt_transpose(const void* v, int ldv, void* vt, int B, int Tp, int H, int dtype, hipStream_t s) {
+    if (Tp % 64 || ldv < 64 * H || ldv % 8) return MHMR_ERR_BAD_SHAPE;
+    const dim3 grid(Tp / 64, H, B);
+    if (dtype == MHMR_DT_F16) hipLaunchKernelGGL((vt_transpose_kernel<MHMR_DT_F16>), grid, dim3(256), 0, s, v, ldv, vt, Tp, H);
+    else hipLaunchKernelGGL((vt_transpose_kernel<MHMR_DT_BF16>), grid, dim3(256), 0, s, v, ldv, vt, Tp, H);
     MHMR_CHECK_LAUNCH();
     return 0;
 }

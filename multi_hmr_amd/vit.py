@@ -374,6 +374,7 @@ class WorkspaceCache:
                 skb = max(_lib.lib().mhmr_splitk_workspace_bytes(Bh * Tp, Cd, kk) for kk in (Cd, 2 * Cd, 4 * Cd))
             if skb:
                 b["splitk"] = z(skb // 4, dtype=torch.float32)
+                b["v16"] = z(Bh * Tp, Cd)            # the merged qkv launch of a short batch (csrc/capi.hip) leaves the V rows here
             d = _lib.VitDesc()
             d.dtype, d.B, d.S, d.C, d.H, d.L = P["dt_id"], Bh, P["S"], Cd, H, P["L"]
             d.G, d.N, d.T, d.Tp, d.Kp = P["G"], N, P["T"], Tp, P["Kp"]
@@ -388,6 +389,7 @@ class WorkspaceCache:
             d.rowstats = b["rowstats"].data_ptr() if P.get("fold") else None
             d.splitk, d.splitk_bytes = (b["splitk"].data_ptr(), skb) if skb else (None, 0)
             d.cpad = P.get("cpad", 0) if not x3 else 0
+            d.v16 = b["v16"].data_ptr() if "v16" in b else None
             parts.append(dict(desc=d, B=Bh, img0=i * Bh, bufs=b))
         ws = dict(parts[0]["bufs"])
         ws["feat32"] = z(B * N, Cd, dtype=torch.float32)

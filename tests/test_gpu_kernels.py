@@ -950,3 +950,37 @@ def test_gemm_masked_output_width(L, name, dt, tdt, tol, K, a_k):
     # the unmasked kernels refuse a width that is not a multiple of 256; the masked form refuses anything but N = n_valid + 128
     assert L.mhmr_gemm16_masked(A.data_ptr(), ka, Wp.data_ptr(), K, M, Np, 256, K, a_k, bp.data_ptr(), gp.data_ptr(), r.data_ptr(), Nv, Tp, H,
                                 _lib.EPI_RESID, dt, None, None, None, None, None, stream()) != 0
+
+
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("fold", [False, True])
+def test_merged_qkv_launch_equals_the_two_launches(L, name, dt, tdt, tol, fold):
+    """mhmr_qkv16 (one launch for Q | K | V + the transpose of the V rows; a short batch) against the Q | K launch and the V^T launch it
+    replaces: the same products in the same order -> bit-identical qk and vt; and against fp64."""
+    B, Tp, C = 2, 512, 256
+    H, M = C // 64, B * Tp
+    g = torch.Generator(device=dev()).manual_seed(11 + fold)
+    A = torch.randn(M, C, generator=g, device=dev()).to(tdt)
+    W = (torch.randn(3 * C, C, generator=g, device=dev()) / math.sqrt(C)).to(tdt)
+    b = torch.randn(3 * C, generator=g, device=dev())
+    rs = torch.stack([torch.randn(M, generator=g, device=dev()) * 0.3, 0.5 + torch.rand(M, generator=g, device=dev())], 1).contiguous()
+    colsum = W.double().sum(1).float().contiguous()
+    qk, v16, vt = (torch.full(s, 7.0, dtype=tdt, device=dev()) for s in ((M, 2 * C), (M, C), (B, H, 64, Tp)))
+    st = (rs.data_ptr(), colsum.data_ptr(), b.data_ptr()) if fold else (None, None, None)
+    _lib.check(L.mhmr_qkv16(A.data_ptr(), C, W.data_ptr(), C, B, Tp, C, H, None if fold else b.data_ptr(), qk.data_ptr(), v16.data_ptr(), vt.data_ptr(),
+                            dt, *st, stream()), "qkv16")
+    qk2, vt2 = torch.full((M, 2 * C), 7.0, dtype=tdt, device=dev()), torch.full((B, H, 64, Tp), 7.0, dtype=tdt, device=dev())
+    Wv, bv, cv = W[2 * C:].contiguous(), b[2 * C:].contiguous(), colsum[2 * C:].contiguous()
+    _lib.check(L.mhmr_gemm16_ln(A.data_ptr(), C, W.data_ptr(), C, M, 2 * C, C, None if fold else b.data_ptr(), None, qk2.data_ptr(), 2 * C, Tp, H,
+                                _lib.EPI_OP16_QK, dt, 0, 0, 0, None, None, *(st if fold else (None, None, None)), stream()), "qk")
+    _lib.check(L.mhmr_gemm16_ln(A.data_ptr(), C, Wv.data_ptr(), C, M, C, C, None if fold else bv.data_ptr(), None, vt2.data_ptr(), 0, Tp, H,
+                                _lib.EPI_VT, dt, 0, 0, 0, None, None, *((rs.data_ptr(), cv.data_ptr(), bv.data_ptr()) if fold else (None, None, None)),
+                                stream()), "vt")
+    assert torch.equal(qk, qk2) and torch.equal(vt, vt2)
+    lin = A.double() @ W.double().T
+    want = (rs[:, 1:2].double() * (lin - rs[:, 0:1].double() * colsum.double()) + b.double()) if fold else lin + b.double()
+    want[:, :C] *= _lib.ATTN_QSCALE
+    assert maxrel(qk, want[:, :2 * C]) < tol
+    perm = swap23(torch.arange(Tp, device=dev()))
+    got_v = vt.float()[..., perm].permute(0, 3, 1, 2).reshape(M, C)
+    assert maxrel(got_v, want[:, 2 * C:]) < tol
