@@ -680,8 +680,13 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(const void* __restrict__
 //   (applied on the copy's source address), which keeps those sixteen rows on sixteen different 16-byte slots; V^T keeps (row >> 1) & 7.
 //   A query's keys are spread over the four lanes j, j + 16, j + 32, j + 48: the row maximum of tile 0, the row sums at the end and the
 //   lone last key's dot product close over them with two lane exchanges each.
-template <int DT>
-__global__ __launch_bounds__(256, 4) void attn16_kernel(const void* __restrict__ qk_, const void* __restrict__ vt_, void* __restrict__ out_,
+// Round-6 experiment forms (variants 7 / 8 / 9 of mhmr_attention16_ex; what mhmr_vit_forward runs is <DT, false, 2>):
+//   EARLY     the next tile's copies are issued right behind the barrier, IN FRONT of the score MFMAs (the slot they fill was last read in
+//             the previous tile, which every wave has left): ~300 cycles more lead for the landing wait at the top of the next tile;
+//   RING = 3  a third K / V^T slot (48 KiB per workgroup: three workgroups per CU instead of four), copies two tiles ahead behind a COUNTED
+//             wait (the newest tile's four copies per thread may still be in flight).
+template <int DT, bool EARLY = false, int RING = 2>
+__global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const void* __restrict__ qk_, const void* __restrict__ vt_, void* __restrict__ out_,
                                                         int T, int Tp, int C, int H, int nqt, float limit, int* __restrict__ flags, int ldo,
                                                         int o8) {
     typedef typename Op<DT>::T Tt;
@@ -751,19 +756,27 @@ __global__ __launch_bounds__(256, 4) void attn16_kernel(const void* __restrict__
     const bool tail1 = (T & (KB - 1)) == 1 && T > KB;
     const int ntile = tail1 ? T / KB : (T + KB - 1) / KB;
     stage(0, 0);
-    int buf = 0, nbuf = 1;
+    if constexpr (RING == 3) stage(ntile > 1 ? 1 : 0, 1);
+    int buf = 0, nbuf = RING - 1;
     for (int jt = 0; jt < ntile; ++jt) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // tile jt has landed: RING == 2: everything this thread issued; RING == 3: all but the newest tile's four copies
+        if constexpr (RING == 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const char* sk = smem + buf * (2 * KV_TILE_BYTES);
         const char* sv = sk + KV_TILE_BYTES;
         const int nbuf_now = nbuf;
-        buf ^= 1;
-        nbuf ^= 1;
+        if constexpr (RING == 3) { buf = buf == 2 ? 0 : buf + 1; nbuf = nbuf == 2 ? 0 : nbuf + 1; }
+        else { buf ^= 1; nbuf ^= 1; }
+        const int jnext = jt + RING - 1 < ntile ? jt + RING - 1 : ntile - 1;      // (past the end: a harmless re-copy keeps the copy count per tile fixed)
         if (!active) {
-            stage(jt + 1 < ntile ? jt + 1 : ntile - 1, nbuf_now);
+            stage(jnext, nbuf_now);
             continue;
+        }
+        if constexpr (EARLY) {
+            stage(jnext, nbuf_now);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- S^T = K . Q^T - m_ref : s[m][xy][qb], lane (j, g) <- keys 32 m + 8 xy + kb_g + 0..3 of query 16 qb + j ----
         f32x4 sc[2][2][2];
@@ -787,7 +800,7 @@ __global__ __launch_bounds__(256, 4) void attn16_kernel(const void* __restrict__
                     for (int qb = 0; qb < 2; ++qb) sc[m][xy][qb] = Op<DT>::mfma16(kf[xy], qf[qb][ks], sc[m][xy][qb]);
             }
         __builtin_amdgcn_s_setprio(0);
-        stage(jt + 1 < ntile ? jt + 1 : ntile - 1, nbuf_now);
+        if constexpr (!EARLY) stage(jnext, nbuf_now);
         __builtin_amdgcn_sched_barrier(0);
         // ---- mask keys >= T (only the last tile can contain them) ----
         if (jt * KB + KB > T) {
@@ -877,7 +890,7 @@ __global__ __launch_bounds__(256, 4) void attn16_kernel(const void* __restrict__
                 for (int e = 0; e < 8; ++e) dot[qb] = __builtin_fmaf((float)qf[qb][ks][e], (float)kf[e], dot[qb]);
         }
         const int klp = (kl & ~12) | ((kl & 4) << 1) | ((kl & 8) >> 1);          // V^T columns are key-permuted (bits 2 <-> 3)
-        float* vl = (float*)(smem + 2 * 2 * KV_TILE_BYTES) + w * 64;
+        float* vl = (float*)(smem + RING * 2 * KV_TILE_BYTES) + w * 64;
         vl[lane2] = (float)vt[((size_t)(b * H + h) * 64 + lane2) * Tp + klp];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        // the strip is written and read by this wave only
 #pragma unroll
@@ -925,15 +938,16 @@ __global__ __launch_bounds__(256, 4) void attn16_kernel(const void* __restrict__
     }
 }
 
+template <bool EARLY = false, int RING = 2>
 int launch_attn16(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit, int* flags,
                   hipStream_t s, int ldo, int o8) {
     const int nqt = (Tp + 127) / 128;
     const int grid = nqt * H * B;
-    const size_t lds = 2 * 2 * KV_TILE_BYTES + 4 * 256;
+    const size_t lds = RING * 2 * KV_TILE_BYTES + 4 * 256;
     if (dtype == MHMR_DT_F16)
-        hipLaunchKernelGGL((attn16_kernel<MHMR_DT_F16>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags, ldo, o8);
+        hipLaunchKernelGGL((attn16_kernel<MHMR_DT_F16, EARLY, RING>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags, ldo, o8);
     else
-        hipLaunchKernelGGL((attn16_kernel<MHMR_DT_BF16>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags, ldo, o8);
+        hipLaunchKernelGGL((attn16_kernel<MHMR_DT_BF16, EARLY, RING>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags, ldo, o8);
     MHMR_CHECK_LAUNCH();
     return 0;
 }
@@ -993,9 +1007,9 @@ int mhmr_launch_attention_ex(const void* qk, const void* vt, void* out, int B, i
 // (GemmArgs::lo8 of the output projection).  Only the default form (variant 6 + its fallback) takes a pitch other than C.
 int mhmr_launch_attention_pitch(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit_log2,
                                 int variant, int* flags, hipStream_t s, int ldo, int o8) {
-    if ((ldo != C || o8 != 0) && (variant != 6 || ldo < C || o8 < 0 || (o8 > 0 && (o8 < 2 * C || o8 + C > 2 * ldo)))) return MHMR_ERR_BAD_ARG;
+    if ((ldo != C || o8 != 0) && (variant < 6 || variant > 9 || ldo < C || o8 < 0 || (o8 > 0 && (o8 < 2 * C || o8 + C > 2 * ldo)))) return MHMR_ERR_BAD_ARG;
     if (C != H * 64 || Tp % 64 || T > Tp || T <= 0 || limit_log2 < 0.f || limit_log2 > 15.f) return MHMR_ERR_BAD_SHAPE;
-    if ((variant == 0 || variant == 6) && flags == nullptr) return MHMR_ERR_BAD_ARG;
+    if ((variant == 0 || (variant >= 6 && variant <= 9)) && flags == nullptr) return MHMR_ERR_BAD_ARG;
     const float limit = exp2f(limit_log2);
     prof_begin(PROF_ATTN, s);
     int rc = 0;
@@ -1016,9 +1030,15 @@ int mhmr_launch_attention_pitch(const void* qk, const void* vt, void* out, int B
             if (!rc) rc = launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
             break;
         }
-        case 6: {     // MODE 3 arithmetic on v_mfma_f32_16x16x32 (attn16_kernel) + the gated textbook fallback
+        case 6:       // MODE 3 arithmetic on v_mfma_f32_16x16x32 (attn16_kernel) + the gated textbook fallback
+        case 7:       // ... with the next tile's copies in front of the score MFMAs
+        case 8:       // ... with a three-slot K / V^T ring (three workgroups per CU)
+        case 9: {     // ... both
             if (flags == nullptr) return MHMR_ERR_BAD_ARG;
-            rc = launch_attn16(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8);
+            rc = variant == 6 ? launch_attn16<false, 2>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8)
+               : variant == 7 ? launch_attn16<true, 2>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8)
+               : variant == 8 ? launch_attn16<false, 3>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8)
+                              : launch_attn16<true, 3>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8);
             if (!rc) rc = launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8);
             break;
         }

@@ -504,9 +504,18 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
         {
             GemmArgs g{d->xn, pit, k.fc1_w, C, Mg, 4 * C, C, k.fc1_b, nullptr, d->hid, 4 * C, nullptr, 0, Tp, d->H, Mg, EPI_OP16_GELU};
             rows(g);
+            // One 896^2 image over all rows is 17 row tiles x 16 column tiles = 272 tiles: one round of the chip + 16 tiles that cost a second.
+            // When the PATCH rows alone fit one round (16 x 16 = 256), fc1 -- and only fc1 -- takes the token-row map and its class rows the
+            // skinny kernel; the padding rows of `hid` are then never written (they stay as allocated: zero) and nobody reads what the
+            // padding rows of the residual stream become.
+            static const bool fc1map_env = !(getenv("MHMR_FC1_ROWMAP") && atoi(getenv("MHMR_FC1_ROWMAP")) == 0);
+            const int ncu = mhmr_cu_count();
+            const bool fc1map = fc1map_env && allrows256 && !nmask && f2 && N % 256 == 0 && (M / 256) * (4 * C / 256) > ncu &&
+                                (B * N / 256) * (4 * C / 256) <= ncu;
+            if (fc1map) { g.M = B * N; g.Mvalid = B * N; g.img_rows = N; g.img_stride = Tp; }
             if (f2) { g.bias = nullptr; g.rowstats = d->rowstats; g.colsum = k.fc1_colsum; g.fbias = k.fc1_b; }
             TRY(mhmr_launch_gemm(g, dt, s));
-            if (rowmap) {
+            if (rowmap || fc1map) {
                 AnyOrder ao_scope(ao);
                 TRY(mhmr_launch_cls_linear_fold((const char*)d->xn + (size_t)cls_row * pit * esz, rowP, k.fc1_w, C, B, 4 * C, C, 0, f2 ? nullptr : k.fc1_b,
                                                 nullptr, (char*)d->hid + (size_t)cls_row * 4 * C * esz, 4 * rowC, 0, C, nullptr, d->H, Tp, 0, 2, dt,

@@ -19,7 +19,11 @@ PATCH = 14
 
 #: default low-half weight passes (tools/precision_study.py): which projections of which blocks also carry the low
 #: half of their weights.  "v+proj@0-11" = the V and the attention output projections of blocks 0..11.  "" = none.
-DEFAULT_WLO = "v+proj@0-11"
+#: Round 6: "proj@0-11" (rounds 3-5: "v+proj@0-11").  Re-measured on the current kernels over the five ViT-B / ViT-L goldens (profiles/
+#: r06_wlo_study_gpu.txt): worst key 5.9e-4 with the output projections of blocks 0-11 alone against 6.05e-4 with V and proj, the bench's own
+#: parity leg 7.2e-4 against 6.9e-4 -- the V low halves bought nothing measurable any more and cost twelve doubled V launches per forward
+#: (-1.3 ms per headline step).  none: 8.3e-4; proj@0-7: 6.4e-4; proj (all 24): 5.4e-4.
+DEFAULT_WLO = "proj@0-11"
 
 
 def default_wlo(embed_dim: int) -> str:
@@ -138,7 +142,10 @@ def fold_eligible(C: int, N: int) -> bool:
     import os
     wide = C % 256 == 0
     # ViT-S (C = 384, round 6): its C-wide linears run as N = 512 with masked columns (mhmr_vit_desc.cpad), always over all rows
-    narrow = C % 128 == 0 and os.environ.get("MHMR_VITS_256", "1") != "0" and os.environ.get("MHMR_LNFOLD_ALLROWS", "1") != "0"
+    # OFF unless MHMR_VITS_256=1: built, parity-green and measured SLOWER at BASELINE's config 2 (16 images, two blocks of 8: 2523-2763 against
+    # 2755-2768 img/s on the 128x128 kernel, one box, interleaved: profiles/r06_session_b.txt): 80 row tiles x 2 column tiles = 160 tiles of
+    # 256x256 are 0.6 rounds of the chip, a quarter of them masked, and K = 384 is six k tiles -- the tile is too coarse for this batch
+    narrow = C % 128 == 0 and os.environ.get("MHMR_VITS_256", "0") == "1" and os.environ.get("MHMR_LNFOLD_ALLROWS", "1") != "0"
     return (os.environ.get("MHMR_LNFOLD", "1") != "0" and os.environ.get("MHMR_ROWMAP", "1") != "0" and "MHMR_GEMM128" not in os.environ and
             ((wide and (N % 256 == 0 or os.environ.get("MHMR_LNFOLD_ALLROWS", "1") != "0")) or (not wide and narrow)))
 

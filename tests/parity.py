@@ -11,7 +11,8 @@ within 1e-3 relative fp tolerance".  Metric: per-tensor relative L2 over all per
                   they read, up to 2x after the decoder) get there: a single f16 pass left `expression` at 1.2e-3 on one of the four
                   BASELINE-size goldens -- 68 % of the error variance is the one-time rounding of the ViT weights to f16 -- so the V and
                   attention-output projections of blocks 0..11 also run the LOW halves of their weights through the matrix pipe
-                  (multi_hmr_amd/vit.py DEFAULT_WLO, DESIGN.md section 3: 7.8e-4 worst over the four cases, +3 % step time).
+                  (multi_hmr_amd/vit.py DEFAULT_WLO; round 6: the output projections of blocks 0-11 alone, worst key 5.9e-4
+                  over the five ViT-B / ViT-L goldens).
   bf16 operands (8-bit significand) miss the contract by 3-8x and are held to 2e-2; they are measured, not the product default.
   MAXTOL          the same keys in the max norm (|err|_inf / |ref|_inf) at BASELINE.json's sizes and on the hostile-weight goldens."""
 import numpy as np

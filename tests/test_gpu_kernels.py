@@ -386,7 +386,7 @@ def _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=None, variant=0):
     else:
         flags = torch.full((L.mhmr_attention_flag_count(B, Tp, H),), 7, dtype=torch.int32, device=dev())   # (the call writes every entry)
         _lib.check(L.mhmr_attention16_ex(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), B, T, Tp, C, H, dt, thr, variant,
-                                         flags.data_ptr() if variant in (0, 4, 5, 6) else None, stream()), "attention_ex")
+                                         flags.data_ptr() if variant in (0, 4, 5, 6, 7, 8, 9) else None, stream()), "attention_ex")
         _attn_run.last_flags = flags
     return out.view(B, Tp, C)
 
@@ -400,7 +400,7 @@ def _attn_ref(q, k, v, T, rows=None):
 
 
 @pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
-@pytest.mark.parametrize("variant", [None, 0, 4, 5, 6])     # None = mhmr_attention16; 0 = 32 queries per wave; 4 / 5 = 64 queries per wave; 6 = 16x16x32 MFMAs
+@pytest.mark.parametrize("variant", [None, 0, 4, 5, 6, 7, 8, 9])     # None = mhmr_attention16; 0 = 32 queries per wave; 4 / 5 = 64 queries per wave; 6 = 16x16x32 MFMAs; 7 / 8 / 9 = its round-6 experiment forms (early copies, three-slot ring, both)
 @pytest.mark.parametrize("B,H,T,pad", [(2, 3, 200, 128), (1, 2, 256, 128), (1, 1, 65, 128), (2, 6, 257, 128), (2, 6, 257, 64), (3, 2, 130, 64),
                                        (1, 2, 577, 64), (2, 1, 40, 64)])
 def test_attention(L, name, dt, tdt, tol, B, H, T, pad, variant):

@@ -160,14 +160,14 @@ def test_token_rows_per_image_rule(monkeypatch):
     # ... and with folded LayerNorms but no row map (N = 8464 is not a multiple of 256): rows per image padded to whole 256-row tiles,
     # whatever the batch size (the fold needs every block linear on the 256x256 kernel over all B * Tp rows)
     assert all(vit.padded_tokens({"C": 1024, "T": 8465, "fold": True}, b) == 8704 for b in (1, 3, 8))
-    assert vit.padded_tokens({"C": 1024, "T": 4097, "fold": True}, 32) == 4160 and vit.fold_eligible(1024, 8464) and vit.fold_eligible(384, 2304)
-    # round 6: ViT-S (C = 384) folds too -- its C-wide linears run as N = 512 with masked columns, always over ALL rows (whole 256-row tiles,
-    # no token-row map); MHMR_VITS_256=0 is the A/B switch back to the 128x128 kernel
+    assert vit.padded_tokens({"C": 1024, "T": 4097, "fold": True}, 32) == 4160 and vit.fold_eligible(1024, 8464) and not vit.fold_eligible(384, 2304)
+    # round 6: ViT-S (C = 384) CAN fold too -- its C-wide linears as N = 512 with masked columns, always over ALL rows (whole 256-row tiles,
+    # no token-row map) -- but that form measured slower at config 2's batch, so it is opt-in (MHMR_VITS_256=1)
     S6 = {"C": 384, "T": 2305, "fold": True, "cpad": 512}
     assert [vit.padded_tokens(S6, b) for b in (1, 8, 16)] == [2560, 2560, 2560] and not vit.row_map(S6, 8)
-    assert vit.default_wlo(384) == "" and vit.default_wlo(768) == vit.default_wlo(1024) == vit.DEFAULT_WLO
-    monkeypatch.setenv("MHMR_VITS_256", "0")
-    assert not vit.fold_eligible(384, 2304) and vit.fold_eligible(768, 2304)
+    assert vit.default_wlo(384) == "" and vit.default_wlo(768) == vit.default_wlo(1024) == vit.DEFAULT_WLO == "proj@0-11"
+    monkeypatch.setenv("MHMR_VITS_256", "1")
+    assert vit.fold_eligible(384, 2304) and vit.fold_eligible(768, 2304)
     monkeypatch.delenv("MHMR_VITS_256")
     # tiny batches (the narrowest linear at most half a round of 256x256 tiles) with folded LayerNorms: all rows through the big GEMMs, no
     # class-row kernels -- 896^2: one image; 672^2: up to three
