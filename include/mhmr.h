@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define MHMR_VERSION 105   /* 105: mhmr_vit_desc.v16 (merged qkv launch of a short batch); mhmr_vit_desc.cpad (ViT-S on the 256x256 kernel: C-wide linears as N = 512 with masked columns); mhmr_vit_desc.{splitk, splitk_bytes}, mhmr_splitk_workspace_bytes, mhmr_gemm16_splitk_resid: split-k residual linears for launches that fill less than half the chip (a batch of one); 104: mhmr_vit_desc.{x3, qkv32, hid32}: the f16x3 precision mode (three 16-bit products per term in every backbone linear, fp32 attention); mhmr_gemm16_ex a_k with K = 3 a_k; mhmr_attention_f32; 103: mhmr_attention16_ex variant 6 (the default of mhmr_vit_forward); mhmr_camera_embed(num_bands), mhmr_hph_desc.cam_dim; mhmr_lbs_consts.basis16 layout (high halves for k < Kb - 64); mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
+#define MHMR_VERSION 105   /* 105: mhmr_vit_desc.cls_pstats (row statistics inside the class-row launches); mhmr_vit_desc.v16 (merged qkv launch of a short batch); mhmr_vit_desc.cpad (ViT-S on the 256x256 kernel: C-wide linears as N = 512 with masked columns); mhmr_vit_desc.{splitk, splitk_bytes}, mhmr_splitk_workspace_bytes, mhmr_gemm16_splitk_resid: split-k residual linears for launches that fill less than half the chip (a batch of one); 104: mhmr_vit_desc.{x3, qkv32, hid32}: the f16x3 precision mode (three 16-bit products per term in every backbone linear, fp32 attention); mhmr_gemm16_ex a_k with K = 3 a_k; mhmr_attention_f32; 103: mhmr_attention16_ex variant 6 (the default of mhmr_vit_forward); mhmr_camera_embed(num_bands), mhmr_hph_desc.cam_dim; mhmr_lbs_consts.basis16 layout (high halves for k < Kb - 64); mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
 
 #define MHMR_OK 0
 #define MHMR_ERR_BAD_ARG (-1)
@@ -145,6 +145,11 @@ typedef struct {
      * of 256x256 tiles (B*Tp/256 * 3C/256 <= CUs): blocks whose V has no low half run Q | K | V as ONE launch -- V row-major into this
      * buffer -- followed by a transpose into `vt`, instead of a Q | K and a V launch of half a round each. */
     void* v16;
+    /* [B, C/16, 2] fp32 or NULL.  Given (with pstats / rowstats, under the token-row map): the class-row launches of proj / fc2 also run the
+     * patch rows' row statistics (extra workgroups of the same launch) and leave block sums of the class rows here, which the class-row
+     * launches of qkv / fc1 turn into (mean, rstd) themselves -- the forward then issues no statistics launch of its own (47 fewer
+     * launches per ViT-L forward).  NULL = mhmr_ln_stats-style launches as before. */
+    float* cls_pstats;
 } mhmr_vit_desc;
 
 /* x: [B,3,S,S] fp32 (ImageNet-normalised).  feat32: [B*N, C] fp32 patch features (token n = y*G + x).

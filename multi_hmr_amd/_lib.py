@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmhmr.so")
 SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "attention_f32.hip", "vit_misc.hip", "vit_cls.hip", "hph.hip", "lbs.hip", "preprocess.hip", "evalm.hip", "anny.hip", "capi.hip"]
-HEADERS = ["mhmr_common.h", "mhmr_internal.h", os.path.join("..", "..", "include", "mhmr.h")]
+HEADERS = ["mhmr_common.h", "mhmr_internal.h", "ln_stats.h", os.path.join("..", "..", "include", "mhmr.h")]
 
 VERSION = 105                       # include/mhmr.h MHMR_VERSION (struct layouts and entry-point semantics)
 DT_BF16, DT_F16 = 0, 1
@@ -106,7 +106,7 @@ class VitDesc(C.Structure):
                 [("patch_w", _vp), ("patch_b", _vp), ("cls_pos0", _vp), ("pos", _vp), ("blocks", C.POINTER(VitBlock)),
                  ("norm_w", _vp), ("norm_b", _vp)] +
                 [(n, _vp) for n in ("a_patch", "resid", "xn", "qk", "vt", "att", "hid", "attn_flags", "pstats", "rowstats")] +
-                [("lo8", _i), ("x3", _i), ("qkv32", _vp), ("hid32", _vp), ("splitk", _vp), ("splitk_bytes", C.c_longlong), ("cpad", _i), ("v16", _vp)])
+                [("lo8", _i), ("x3", _i), ("qkv32", _vp), ("hid32", _vp), ("splitk", _vp), ("splitk_bytes", C.c_longlong), ("cpad", _i), ("v16", _vp), ("cls_pstats", _vp)])
 
 
 class HphLayer(C.Structure):

@@ -33,7 +33,7 @@ int mhmr_launch_cls_linear(const void* A, long long a_stride, const void* W, int
 int mhmr_launch_cls_linear_fold(const void* A, long long a_stride, const void* W, int ldw, int B, int N, int K, int a_k, const float* bias,
                                 const float* gamma, void* out, long long o_stride, int n_base, int C, void* vt, int H, int Tp, int vcol, int epi,
                                 int dtype, const float* rowstats, long long rs_stride, const float* colsum, const float* fbias, void* x16,
-                                long long x_stride, hipStream_t s);
+                                long long x_stride, hipStream_t s, const ClsStats* st = nullptr);
 int mhmr_launch_ln_stats(const float* pstats, const float* resid, float* rowstats, int B, int N, int Tp, int C, float eps, hipStream_t s);
 int mhmr_launch_attention_f32(const float* qkv, void* out, int B, int T, int Tp, int C, int H, int dtype, hipStream_t s);
 int mhmr_launch_im2col_pair(const float* x, void* a, int B, int S, int G, int Kp, int dtype, hipStream_t s);
@@ -405,6 +405,19 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) ao = false;
     }
+    // Row statistics inside the class-row launches (vit_cls.hip, round 6): with mhmr_vit_desc.cls_pstats the residual class-row launch of
+    // proj / fc2 also carries the patch rows' statistics (extra workgroups) and leaves block sums of the class rows, from which the class-row
+    // consumers take (mean, rstd) themselves: no ln_stats launch at all under the token-row map.  MHMR_CLS_STATS=0: the separate launches.
+    const bool cls_stats_env = !(getenv("MHMR_CLS_STATS") && atoi(getenv("MHMR_CLS_STATS")) == 0);     // (read per call: tests switch it in-process)
+    const bool cst = cls_stats_env && rowmap && fold && !lo8 && d->cls_pstats && C % 128 == 0 && C <= 1024;
+    ClsStats cs_consume, cs_produce, cs_produce_stats;
+    if (cst) {
+        cs_consume.cls_pstats = d->cls_pstats; cs_consume.cls_nblk = C / 16; cs_consume.cls_C = C;
+        cs_produce = cs_consume;
+        cs_produce_stats = cs_consume;
+        cs_produce_stats.st_pstats = d->pstats; cs_produce_stats.st_rowstats = d->rowstats;
+        cs_produce_stats.st_B = B; cs_produce_stats.st_N = N; cs_produce_stats.st_Tp = Tp; cs_produce_stats.st_C = C;
+    }
     bool stats_fresh = false;            // rowstats already hold the statistics of the current residual rows
     auto resid_linear = [&](GemmArgs& g) -> int {
         int ks = 0, S = 0;
@@ -471,15 +484,16 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
             if (rowmap) {
                 const char* xr = (const char*)d->xn + (size_t)cls_row * pit * esz;
                 char* qr = (char*)d->qk + (size_t)cls_row * 2 * C * esz;
-                const float* st = f1 ? cls_stats : nullptr;
+                const float* st = (f1 && !cst) ? cls_stats : nullptr;
+                const ClsStats* cs = (f1 && cst) ? &cs_consume : nullptr;
                 // (Q | K and V separately when V carries a low half: different k extents)
                 const int nqk = k.v_w2 ? 2 * C : 3 * C;
                 TRY(mhmr_launch_cls_linear_fold(xr, rowP, k.qkv_w, C, B, nqk, C, 0, f1 ? nullptr : k.qkv_b, nullptr, qr, 2 * rowC, 0, C, d->vt, d->H,
-                                                Tp, vcol, 0, dt, st, 2LL * Tp, k.qkv_colsum, k.qkv_b, nullptr, 0, s));
+                                                Tp, vcol, 0, dt, st, 2LL * Tp, k.qkv_colsum, k.qkv_b, nullptr, 0, s, cs));
                 if (k.v_w2)
                     TRY(mhmr_launch_cls_linear_fold(xr, rowP, v_wc, v_kc, B, C, v_kc, v_akc, f1 ? nullptr : k.qkv_b + 2 * C, nullptr, qr, 2 * rowC, 2 * C, C,
                                                     d->vt, d->H, Tp, vcol, 0, dt, st, 2LL * Tp, f1 ? k.qkv_colsum + 2 * C : nullptr,
-                                                    k.qkv_b + 2 * C, nullptr, 0, s));
+                                                    k.qkv_b + 2 * C, nullptr, 0, s, cs));
             }
             }
         }
@@ -493,10 +507,14 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
             masked(g);
             TRY(resid_linear(g));
             AnyOrder ao_scope(ao);
-            if (rowmap)
+            if (rowmap) {
+                // (with cst: + the patch rows' statistics for norm2, when the next linear consumes them)
+                const ClsStats* cs = !cst ? nullptr : f2 ? &cs_produce_stats : &cs_produce;
                 TRY(mhmr_launch_cls_linear_fold((const char*)d->att + (size_t)cls_row * pit * esz, rowP, p_wc, p_kc, B, C, p_kc, p_akc, k.proj_b, k.ls1,
                                                 d->resid + (size_t)cls_row * C, rowC, 0, C, nullptr, d->H, Tp, 0, 1, dt, nullptr, 0, nullptr, nullptr,
-                                                fold ? (char*)d->xn + (size_t)cls_row * pit * esz : nullptr, rowP, s));
+                                                fold ? (char*)d->xn + (size_t)cls_row * pit * esz : nullptr, rowP, s, cs));
+                if (cst && f2) stats_fresh = true;
+            }
         }
         // x = x + ls2 * fc2(gelu(fc1(norm2(x))))
         if (f2) { if (!stats_fresh) TRY(ln_stats()); }
@@ -519,7 +537,8 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
                 AnyOrder ao_scope(ao);
                 TRY(mhmr_launch_cls_linear_fold((const char*)d->xn + (size_t)cls_row * pit * esz, rowP, k.fc1_w, C, B, 4 * C, C, 0, f2 ? nullptr : k.fc1_b,
                                                 nullptr, (char*)d->hid + (size_t)cls_row * 4 * C * esz, 4 * rowC, 0, C, nullptr, d->H, Tp, 0, 2, dt,
-                                                f2 ? cls_stats : nullptr, 2LL * Tp, k.fc1_colsum, k.fc1_b, nullptr, 0, s));
+                                                (f2 && !cst) ? cls_stats : nullptr, 2LL * Tp, k.fc1_colsum, k.fc1_b, nullptr, 0, s,
+                                                (f2 && cst) ? &cs_consume : nullptr));
             }
             GemmArgs g2{d->hid, 4 * C, k.fc2_w, 4 * C, Mg, C, 4 * C, k.fc2_b, k.ls2, d->resid, C, nullptr, 0, Tp, d->H, Mg, EPI_RESID};
             rows(g2);
@@ -531,10 +550,15 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
             masked(g2);
             TRY(resid_linear(g2));
             AnyOrder ao_scope2(ao);
-            if (rowmap)
+            if (rowmap) {
+                // (with cst: + the patch rows' statistics for the NEXT block's norm1, when that block folds it)
+                const bool next_f1 = l + 1 < d->L && fold && (d->blocks[l + 1].flags & 1);
+                const ClsStats* cs = !cst ? nullptr : next_f1 ? &cs_produce_stats : &cs_produce;
                 TRY(mhmr_launch_cls_linear_fold((const char*)d->hid + (size_t)cls_row * 4 * C * esz, 4 * rowC, k.fc2_w, 4 * C, B, C, 4 * C, 0, k.fc2_b,
                                                 k.ls2, d->resid + (size_t)cls_row * C, rowC, 0, C, nullptr, d->H, Tp, 0, 1, dt, nullptr, 0, nullptr,
-                                                nullptr, fold ? (char*)d->xn + (size_t)cls_row * pit * esz : nullptr, rowP, s));
+                                                nullptr, fold ? (char*)d->xn + (size_t)cls_row * pit * esz : nullptr, rowP, s, cs));
+                if (cst && next_f1) stats_fresh = true;
+            }
         }
     }
     return mhmr_launch_final_norm(d->resid, d->norm_w, d->norm_b, ctx16, ldctx, feat32, B, d->N, Tp, C, 1e-6f, dt, s);

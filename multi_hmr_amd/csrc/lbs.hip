@@ -340,6 +340,15 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const mhmr_lbs_consts c, c
 //   phase D  the operand rows leave as 16-byte chunks: 160 chunks over 256 lanes, one pass
 // Every expression is the one of lbs_pose_person (same operand order, same contraction), so the results are bit-identical to it
 // (tests/test_gpu_kernels.py::test_lbs_fused_launch_is_bit_identical... compares against the fused launch, which keeps the one-wave form).
+#ifdef MHMR_LBS_STAMPS      // tools/lbs_pose_timeline.py: wall-clock (100 MHz) stamps of the pose kernel, debug build only
+__device__ unsigned long long* g_pose_stamps;
+#define POSE_STAMP(i)                                                                                                               \
+    do {                                                                                                                            \
+        if (g_pose_stamps && (threadIdx.x & 63) == 0) g_pose_stamps[(size_t)blockIdx.x * 16 + (i)] = wall_clock64();               \
+    } while (0)
+#else
+#define POSE_STAMP(i)
+#endif
 constexpr int POSE_MAXLEVEL = 56;          // a tree of NJ = 55 joints has at most 55 levels: every topology fits
 struct __attribute__((aligned(16))) Pose4Lds {
     PoseLds L;
@@ -362,6 +371,7 @@ __global__ __launch_bounds__(256) void lbs_pose4_kernel(const mhmr_lbs_consts c,
     float (&sF)[LBS_KB_POSE] = L.sF; float (&sA)[12][64] = L.sA;
     const int p = (int)blockIdx.x, tid = threadIdx.x, j = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (w == 0) POSE_STAMP(0);
     const int ngr = Pp / 16, grp = p >> 4, pin = p & 15, nst = c.Kb / 32;
     typedef Op<MHMR_DT_F16>::V8 H8;
     // phase D (also the padding rows of both operand matrices: zero = true)
@@ -518,7 +528,9 @@ __global__ __launch_bounds__(256) void lbs_pose4_kernel(const mhmr_lbs_consts c,
         }
         if (j == 0) S.sMaxDepth = maxdepth;
     }
+    POSE_STAMP(1 + w);          // 1..4: the four roles of phase A done (their LDS stores issued)
     __syncthreads();
+    if (w == 0) POSE_STAMP(5);
     // ---------------- phase B: the kinematic chain, one tree level at a time, one lane per (joint, element) ----------------
     const int maxdepth = S.sMaxDepth;
     for (int level = 0; level <= maxdepth; ++level) {
@@ -546,6 +558,7 @@ __global__ __launch_bounds__(256) void lbs_pose4_kernel(const mhmr_lbs_consts c,
         __syncthreads();
     }
     // ---------------- phase C: recentring, then the per-joint read-outs ----------------
+    if (w == 0) POSE_STAMP(6);
     if (tid == 0) {
         float R0[9], cc[3];
 #pragma unroll
@@ -561,6 +574,7 @@ __global__ __launch_bounds__(256) void lbs_pose4_kernel(const mhmr_lbs_consts c,
         for (int a = 0; a < 3; ++a) { sX[9 + a] = sTw[0][a]; sX[12 + a] = sX[24 + a] - cc[a]; }
     }
     __syncthreads();
+    if (w == 0) POSE_STAMP(7);
     if (w == 2 && j < 24) xf[(size_t)p * 24 + j] = sX[j];
     if (w == 0 && j < NJ) {
         float R0[9], Rw[9], Rf[9], tp[3], tt[3], u[3];
@@ -594,7 +608,13 @@ __global__ __launch_bounds__(256) void lbs_pose4_kernel(const mhmr_lbs_consts c,
         j2d[((size_t)p * 127 + j) * 2 + 1] = pr[1];
     }
     __syncthreads();
+    if (w == 0) POSE_STAMP(8);
     flush(false);
+    if (w == 0) POSE_STAMP(9);
+#ifdef MHMR_LBS_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (w == 0) POSE_STAMP(10);          // this wave's stores have left
+#endif
 }
 
 #ifdef MHMR_LBS_STAMPS      // tools/lbs_timeline.py: per-workgroup s_memtime stamps of wave 0 (debug build only, never in libmhmr.so)
@@ -1007,6 +1027,9 @@ __global__ __launch_bounds__(64 * (LBS_NC + LBS_NL), 3) void lbs_vertex_kernel(c
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ngroups = Pp / 16;
     LBS_STAMP(0);
+#ifdef MHMR_LBS_STAMPS
+    if (g_lbs_stamps && threadIdx.x == 0) g_lbs_stamps[(size_t)blockIdx.x * 16 + 12] = wall_clock64();      // (for tools/lbs_pose_timeline.py: the gap behind the pose kernel)
+#endif
     // every wave passes the same LBS_NE barriers
     if (w >= LBS_NC) {
         lbs_loader<false>(c, xf, P, ngroups, g0, smem, w - LBS_NC, (int)blockIdx.x, nullptr, 0, Pp);
@@ -1022,6 +1045,7 @@ __global__ __launch_bounds__(64 * (LBS_NC + LBS_NL), 3) void lbs_vertex_kernel(c
 
 #ifdef MHMR_LBS_STAMPS
 extern "C" int mhmr_debug_lbs_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lbs_stamps), &p, sizeof(p)); }
+extern "C" int mhmr_debug_pose_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pose_stamps), &p, sizeof(p)); }
 #endif
 
 static int lbs_forward_impl(const mhmr_lbs_consts* c, const float* rotvec, const float* betas, const float* expr,

@@ -111,6 +111,18 @@ inline void mhmr_launch_kernel(F kernel, dim3 grid, dim3 block, size_t lds, hipS
     else hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
 }
 
+// Row statistics carried by the class-row kernel's launches (vit_cls.hip, round 6).  cls_pstats [rows][cls_nblk][2]: block sums of the class
+// rows (written by epi = 1, read by epi = 0 / 2 in place of `rowstats`); st_*: the patch rows' statistics as extra workgroups of an epi = 1
+// launch (st_pstats = the big GEMM's block sums, st_rowstats = its consumers' (mean, rstd); st_B images x st_N patch rows of st_Tp-row images).
+struct ClsStats {
+    float* cls_pstats = nullptr;
+    int cls_nblk = 0, cls_C = 0;
+    float eps = 1e-6f;
+    const float* st_pstats = nullptr;
+    float* st_rowstats = nullptr;
+    int st_B = 0, st_N = 0, st_Tp = 0, st_C = 0;
+};
+
 // ---- per-kernel-family hipEvent profiling (bench.py roofline leg) ----
 enum ProfKind { PROF_GEMM = 0, PROF_ATTN = 1, PROF_LBS = 2, PROF_KINDS = 3 };
 void prof_begin(int kind, hipStream_t s);

@@ -3,6 +3,7 @@
 // that emits the patch features both as fp32 and as the 16-bit cross-attention context operand.
 #include "mhmr_common.h"
 #include "mhmr_internal.h"
+#include "ln_stats.h"
 
 namespace {
 
@@ -127,33 +128,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 //   class row (b, N):  its residual row is updated by the skinny kernel (csrc/vit_cls.hip), which leaves no block sums: one wave reads
 //                      the fp32 row and takes the centred variance, like layernorm_kernel
 // rowstats[b * Tp + t] = (mean, rstd).  grid = ceil(B * N / 32) + ceil(B / 4) blocks of 256 threads.
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ pstats, const float* __restrict__ resid,
                                                        float* __restrict__ rowstats, int B, int N, int Tp, int C, int nblk, float eps,
                                                        int patch_blocks) {
     if ((int)blockIdx.x < patch_blocks) {
-        // eight lanes per row, two blocks (one 16-byte load) per lane: a wave reads 8 rows x 128 B as whole lines; the eight partial
-        // sums meet on the VALU (quad xor 1, quad xor 2, half-row mirror): a fixed order, bit-reproducible
-        const int gid = blockIdx.x * 256 + threadIdx.x;
-        const int m = gid >> 3, part = gid & 7;
-        const bool live = m < B * N && 2 * part < nblk;
-        const int mm = m < B * N ? m : B * N - 1;
-        const int b = mm / N, n = mm - b * N;
-        const size_t row = (size_t)b * Tp + n;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (live) v = *(const f32x4*)(pstats + row * nblk * 2 + part * 4);
-        float s1 = v[0] + v[2], s2 = v[1] + v[3];
-        s1 = dpp_add<0xB1>(s1); s2 = dpp_add<0xB1>(s2);
-        s1 = dpp_add<0x4E>(s1); s2 = dpp_add<0x4E>(s2);
-        s1 = dpp_add<0x141>(s1); s2 = dpp_add<0x141>(s2);
-        if (part == 0 && m < B * N) {
-            const float mean = s1 * (1.0f / C);
-            const float var = fmaxf(s2 * (1.0f / C) - mean * mean, 0.f);
-            *(f32x2*)(rowstats + row * 2) = (f32x2){mean, rsqrtf(var + eps)};
-        }
+        ln_stats_patch_rows((int)(blockIdx.x * 256 + threadIdx.x), pstats, rowstats, B, N, Tp, C, nblk, eps);      // (ln_stats.h)
     } else {
         const int b = (blockIdx.x - patch_blocks) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
         if (b >= B) return;

@@ -375,6 +375,8 @@ class WorkspaceCache:
                          attn_flags=z(_lib.lib().mhmr_attention_flag_count(Bh, Tp, H), dtype=torch.int32))
             if P.get("fold"):
                 b.update(pstats=z(Bh * Tp, Cd // 64, 2, dtype=torch.float32), rowstats=z(Bh * Tp, 2, dtype=torch.float32))
+            if P.get("fold") and not x3 and row_map(P, Bh):
+                b["cls_pstats"] = z(Bh, Cd // 16, 2, dtype=torch.float32)       # block sums of the class rows (csrc/vit_cls.hip)
             # split-k residual linears (csrc/capi.hip): only the all-rows form of a tiny batch has launches short enough to be split
             skb = 0
             if P.get("fold") and not x3 and not P.get("lo8") and Tp % 256 == 0 and not row_map(P, Bh):
@@ -397,6 +399,7 @@ class WorkspaceCache:
             d.splitk, d.splitk_bytes = (b["splitk"].data_ptr(), skb) if skb else (None, 0)
             d.cpad = P.get("cpad", 0) if not x3 else 0
             d.v16 = b["v16"].data_ptr() if "v16" in b else None
+            d.cls_pstats = b["cls_pstats"].data_ptr() if "cls_pstats" in b else None
             parts.append(dict(desc=d, B=Bh, img0=i * Bh, bufs=b))
         ws = dict(parts[0]["bufs"])
         ws["feat32"] = z(B * N, Cd, dtype=torch.float32)
