@@ -71,10 +71,12 @@ constexpr float BAND = 8.f;                 // MODE 2: half-width of the band ar
 // flags: four ints per workgroup (logical id), one per wave.  MODE 3 writes every one of them (1 = this workgroup's result must be
 // recomputed, else 0: no memset in front of the launch); MODE 1 with a
 // non-null flags pointer returns immediately unless flags[wg] != 0.
+// (attn_body: the kernel for logical workgroup `bid`; attn_kernel = one workgroup per block; attn_fallback_kernel = the gated MODE 1 pass of
+// the MODE 3 forms as a SMALL grid that scans the flags -- further down)
 template <int DT, int NW, int RING, int MODE>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
+__device__ __forceinline__ void attn_body(
     const void* __restrict__ qk_, const void* __restrict__ vt_, void* __restrict__ out_, int T, int Tp, int C, int H, int nqt,
-    float limit, int* __restrict__ flags, int ldo, int o8) {
+    float limit, int* __restrict__ flags, int ldo, int o8, const int bid) {
     // ldo: row pitch of `out` in elements (C, or wider when a row also carries its bf8 copy); o8 > 0: byte offset of that copy inside a row
     typedef typename Op<DT>::T Tt;
     typedef typename Op<DT>::V8 V8;
@@ -85,13 +87,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
 
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    if constexpr (MODE == 1) {
-        if (flags != nullptr) {                               // fallback launch: only the flagged workgroups are recomputed
-            const int4 f = *(const int4*)(flags + 4 * bid);   // (one flag per wave of the MODE 3 workgroup, written unconditionally)
-            if ((f.x | f.y | f.z | f.w) == 0) return;
-        }
-    }
     const int qt = bid % nqt, bh = bid / nqt;
     const int b = bh / H, h = bh - b * H;
     constexpr int QB = 32 * NW;
@@ -365,6 +360,44 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
             *(V4*)(op + 32 * ds + 8 * rg) = v;
             if (o8 > 0) *(uint32_t*)(op8 + 32 * ds + 8 * rg) = pack_bf8x4(f[0], f[1], f[2], f[3]);      // the output projection's fp8 low-half range
         }
+}
+
+template <int DT, int NW, int RING, int MODE>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
+    const void* __restrict__ qk_, const void* __restrict__ vt_, void* __restrict__ out_, int T, int Tp, int C, int H, int nqt,
+    float limit, int* __restrict__ flags, int ldo, int o8) {
+    attn_body<DT, NW, RING, MODE>(qk_, vt_, out_, T, Tp, C, H, nqt, limit, flags, ldo, o8, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// The gated textbook pass behind a MODE 3 form (round 6).  Rounds 2-5 launched the textbook kernel over the WHOLE grid and let every
+// workgroup read its four flags and return: 16 896 workgroups at the headline, 9-11 us per launch for nothing (nothing is ever flagged on
+// real or random data), 24 times per forward.  Here a workgroup scans 256 workgroups' flags with one 16-byte load per thread -- the grid is
+// ceil(nwg / 256) workgroups: 66 at the headline, 3 for a batch of one -- and recomputes the flagged ones of its slice one after the other
+// (the rare path trades parallelism for the common path's launch).
+template <int DT>
+__global__ __launch_bounds__(256, 4) void attn_fallback_kernel(const void* __restrict__ qk_, const void* __restrict__ vt_, void* __restrict__ out_,
+                                                               int T, int Tp, int C, int H, int nqt, float limit, int* __restrict__ flags,
+                                                               int ldo, int o8, int nwg) {
+    __shared__ unsigned long long smask[4];
+    const int tid = threadIdx.x, wg = blockIdx.x * 256 + tid;
+    int any = 0;
+    if (wg < nwg) {
+        const int4 f = *(const int4*)(flags + 4 * wg);        // (one flag per wave of the MODE 3 workgroup, written unconditionally)
+        any = (f.x | f.y | f.z | f.w) != 0;
+    }
+    const unsigned long long m = __ballot(any);
+    if ((tid & 63) == 0) smask[tid >> 6] = m;
+    __syncthreads();
+    if ((smask[0] | smask[1] | smask[2] | smask[3]) == 0ull) return;
+    for (int q = 0; q < 4; ++q) {
+        unsigned long long mm = smask[q];
+        while (mm) {
+            const int bit = __builtin_ctzll(mm);
+            mm &= mm - 1;
+            attn_body<DT, 4, 2, 1>(qk_, vt_, out_, T, Tp, C, H, nqt, limit, nullptr, ldo, o8, blockIdx.x * 256 + 64 * q + bit);
+            __syncthreads();                                  // the K / V ring of the next flagged workgroup re-uses this one's LDS
+        }
+    }
 }
 
 
@@ -966,6 +999,21 @@ int launch_attn64(const void* qk, const void* vt, void* out, int B, int T, int T
     return 0;
 }
 
+// the gated textbook pass over the flags a MODE 3 form (128-query workgroup numbering) has left
+int launch_attn_fallback(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit, int* flags,
+                         hipStream_t s, int ldo = 0, int o8 = 0) {
+    if (ldo <= 0) ldo = C;
+    const int nqt = (Tp + 127) / 128, nwg = nqt * H * B;
+    const int grid = (nwg + 255) / 256;
+    const size_t lds = 2 * 2 * KV_TILE_BYTES + 4 * 256;
+    if (dtype == MHMR_DT_F16)
+        hipLaunchKernelGGL((attn_fallback_kernel<MHMR_DT_F16>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags, ldo, o8, nwg);
+    else
+        hipLaunchKernelGGL((attn_fallback_kernel<MHMR_DT_BF16>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags, ldo, o8, nwg);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int NW, int RING, int MODE>
 int launch_attn(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit, int* flags,
                 hipStream_t s, int ldo = 0, int o8 = 0) {
@@ -1016,7 +1064,7 @@ int mhmr_launch_attention_pitch(const void* qk, const void* vt, void* out, int B
     switch (variant) {
         case 0: {
             rc = launch_attn<4, 2, 3>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
-            if (!rc) rc = launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);      // returns at once where flags[wg] == 0
+            if (!rc) rc = launch_attn_fallback(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);      // recomputes the flagged workgroups only
             break;
         }
         case 1: rc = launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, nullptr, s); break;
@@ -1027,7 +1075,7 @@ int mhmr_launch_attention_pitch(const void* qk, const void* vt, void* out, int B
             if (flags == nullptr) return MHMR_ERR_BAD_ARG;
             rc = variant == 4 ? launch_attn64<3>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s)
                               : launch_attn64<2>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
-            if (!rc) rc = launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
+            if (!rc) rc = launch_attn_fallback(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s);
             break;
         }
         case 6:       // MODE 3 arithmetic on v_mfma_f32_16x16x32 (attn16_kernel) + the gated textbook fallback
@@ -1039,7 +1087,7 @@ int mhmr_launch_attention_pitch(const void* qk, const void* vt, void* out, int B
                : variant == 7 ? launch_attn16<true, 2>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8)
                : variant == 8 ? launch_attn16<false, 3>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8)
                               : launch_attn16<true, 3>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8);
-            if (!rc) rc = launch_attn<4, 2, 1>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8);
+            if (!rc) rc = launch_attn_fallback(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8);
             break;
         }
         default: return MHMR_ERR_BAD_ARG;

@@ -47,7 +47,7 @@ int mhmr_launch_loc(const float* offset, const int* det_y, const int* det_x, int
 
 thread_local int g_mhmr_anyorder = 0;        // mhmr_internal.h: the next launches of this host thread go out without the AQL barrier bit
 #ifndef MHMR_ANYORDER_DEFAULT
-#define MHMR_ANYORDER_DEFAULT 0
+#define MHMR_ANYORDER_DEFAULT 1      // +0.1 ... +0.8 % on the headline step in six of six interleaved A/B pairs (profiles/r06_session_a.txt, _c.txt)
 #endif
 namespace {
 struct AnyOrder {       // scope guard

@@ -101,8 +101,10 @@ int mhmr_cu_count();
 // the previous kernel of the stream to finish before dispatching this one).  capi.hip sets the thread-local flag around launches whose
 // inputs were complete before the PREVIOUS launch started and whose outputs nothing touches until the next ordinary launch (which waits
 // for everything before it): the V projection behind the Q | K projection, the class-row linears behind the big GEMM of the same
-// linear.  Their workgroups then start on the CUs the persistent GEMM in front of them frees first, i.e. inside its tail, instead of
-// behind its last workgroup.  MHMR_ANYORDER=0 switches it off (A/B measurements); never set while a stream is being captured.
+// linear.  MEASURED (round 6, tools/ubench/anyorder.hip + a kernel trace of the forward, profiles/r06_session_a.txt / _b.txt): on gfx950 /
+// ROCm 7.2 such a kernel still starts only after the kernel in front of it has finished -- no overlap (hip_ext.h says as much: "not
+// supported on GFX9xx") -- but 0.5 us earlier, and the headline step is 0.1-0.8 % faster in six of six interleaved A/B pairs.  So: on by
+// default for what it is, a cheaper boundary.  MHMR_ANYORDER=0 switches it off (A/B measurements); never set while a stream is being captured.
 extern thread_local int g_mhmr_anyorder;
 #include <hip/hip_ext.h>
 template <typename F, typename... Args>

@@ -62,6 +62,21 @@ PRECISIONS = ("f16", "fp16", "bf16", "f16x3", "auto")
 LOGIT_GAIN_LIMIT = 4.0
 
 
+def logit_gain_limit(tokens: int | None = None) -> float:
+    """The spread above which 'auto' packs a checkpoint as f16x3, as a function of the tokens per image (round 6).
+
+    Measured (tools/auto_rule_probe.py; full-depth ViT-L, one image, a ladder between the seeded weights and `hostile_w`; plain f16 against
+    the fp32 CPU reference path, worst key): plain f16 leaves 1e-3 at a steepest-block spread of ~6.5 at 448^2 (1 025 tokens; profiles/
+    r05_auto_rule_probe.txt), ~5.5 at 896^2 (4 097: 6.9e-4 at 4.5, 1.2e-3 at 6.2) and ~4.7 at 1288^2 (8 465: 9.1e-4 at 4.5, 1.7e-3 at
+    6.2; profiles/r06_auto_rule_probe_{896,1288}.txt): longer key sets average MORE rounded terms per softmax row and the error of a
+    steep softmax grows with them, roughly as tokens^0.15.  4.0 switches before the contract is lost at every BASELINE size (margin 1.6x /
+    1.4x / 1.2x); above 4 097 tokens the limit follows the measured slope down -- 4 (4097 / tokens)^0.25: 3.3 at 1288^2 -- so that the
+    margin does not shrink further with resolutions nobody measured.  Never above 4.0, never below 3.0."""
+    if not tokens or tokens <= 4097:
+        return LOGIT_GAIN_LIMIT
+    return max(3.0, LOGIT_GAIN_LIMIT * (4097.0 / float(tokens)) ** 0.25)
+
+
 def logit_gain(enc) -> list:
     """Per block: the standard deviation, ACROSS THE KEYS of one query, of the pre-softmax attention logits (natural-log units) that the
     block's weights produce from a LayerNorm output with unit-variance, independent channels -- rms over the heads.
@@ -90,15 +105,16 @@ def logit_gain(enc) -> list:
     return out
 
 
-def resolve_precision(enc, precision: str) -> str:
-    """'auto' -> 'f16' or 'f16x3' from the weights (``logit_gain``); anything else is returned as given ('fp16' = 'f16')."""
+def resolve_precision(enc, precision: str, tokens: int | None = None) -> str:
+    """'auto' -> 'f16' or 'f16x3' from the weights (``logit_gain``) and the tokens per image (``logit_gain_limit``); anything else is
+    returned as given ('fp16' = 'f16')."""
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {list(PRECISIONS)}")
     if precision == "fp16":
         return "f16"
     if precision != "auto":
         return precision
-    return "f16x3" if max(logit_gain(enc)) > LOGIT_GAIN_LIMIT else "f16"
+    return "f16x3" if max(logit_gain(enc)) > logit_gain_limit(tokens) else "f16"
 
 
 def triple(w: torch.Tensor, tdt) -> torch.Tensor:
@@ -157,7 +173,7 @@ def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = N
     interpolated to the G x G grid on the host (``packing.interpolate_pos_embed``), the patch-embed weight flattened (c, py, px)
     and zero-padded to Kp = 640.  The returned dict owns every tensor the block descriptors point at (``keep``)."""
     requested = precision
-    precision = resolve_precision(enc, precision)
+    precision = resolve_precision(enc, precision, tokens=(img_size // PATCH) ** 2 + 1)
     x3 = precision == "f16x3"
     dt_id, tdt = packing.OP_DTYPES["f16" if x3 else precision]
     Cd, H, L = enc.embed_dim, enc.num_heads, len(enc.blocks)
@@ -180,7 +196,7 @@ def pack_encoder(enc, img_size: int, precision: str, device, wlo: str | None = N
         # and allocates two fp32 workspaces of B x Tp x 3C / 4C; advisor finding of round 5)
         import warnings
         warnings.warn(f"multi_hmr_amd: precision='auto' resolved to 'f16x3' for this checkpoint: steepest attention-logit spread "
-                      f"{max(P['logit_gain']):.2f} > {LOGIT_GAIN_LIMIT} (vit.logit_gain; per block: min {min(P['logit_gain']):.2f}, "
+                      f"{max(P['logit_gain']):.2f} > {logit_gain_limit(T):.2f} (vit.logit_gain / logit_gain_limit at {T} tokens; per block: min {min(P['logit_gain']):.2f}, "
                       f"mean {sum(P['logit_gain']) / len(P['logit_gain']):.2f}).  f16 operand pairs with three products per term and an fp32 "
                       f"attention keep the 1e-3 contract on such weights at about 4x the time of plain f16; Model(precision='f16') forces "
                       f"the fast path (tools/checkpoint_report.py and tools/parity_table.py say what that costs on these weights).",

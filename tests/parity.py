@@ -45,6 +45,25 @@ def tolerance(key, precision):
 #: rms is 3e-4 -- and, on the hostile-mean golden, `v2d` (1.7e-3).  The gate is therefore 2e-3: the max-norm form of the 1e-3 contract
 #: is NOT met on those two keys, and this constant says by how much.
 MAXTOL = {"f16": 2e-3, "bf16": 4e-2}
+#: Round 6: the gate is PER KEY (maxtol() below).  Why `rotmat` cannot meet 1e-3 in the max norm while its relative L2 error is 2e-4
+#: (tools/rotmat_amplification.py, profiles/r06_rotmat_amplification.txt; fp64, on the goldens' own 6D read-outs): the reference's
+#: 6D -> rotation decode (utils/humans.py:12-22) is a Gram-Schmidt that divides by |a1| and |a2 - (b1.a2) b1|; the seeded heads produce
+#: joints whose second column is nearly parallel to the first (|a2_perp| down to 0.10-0.22 against a median of 1.0), where the decode
+#: amplifies a perturbation 10-19x.  A WHITE error of relative L2 2e-4 on the 6D read-out -- what the f16 backbone leaves -- comes out as
+#: rotmat rel-L2 2.3e-4 (x1.1) and max norm 1.2-2.0e-3 (mean over draws; 2.1-3.0e-3 the worst of 32), at every BASELINE size; even the
+#: f16x3 mode (rel-L2 1.0e-4) lands at 0.6-1.1e-3.  At 1288^2 (20 persons, amplification up to 19x) a white 3e-4 comes out at 3.1e-3 in the
+#: mean; measured on the round-6 build: 0.7 / 1.5 / 2.4e-3 at 896^2 / 672^2 / 1288^2 with rel-L2 2.2-2.8e-4 (the statistic is the maximum of
+#: 4-10 thousand heavy-tailed entries: it moves by 2x with any change of rounding order).  So: 3e-3 for `rotmat`, 1.5e-3 for the two PIXEL
+#: keys downstream of the amplified joints (`v2d` 1.1-1.3e-3 on the hostile-mean golden), 1e-3 -- the contract's own number -- for every
+#: other key (rounds 4-5: 2e-3 for all of them).
+MAXTOL_F16 = {"rotmat": 3e-3, "v2d": 1.5e-3, "j2d": 1.5e-3}
+
+
+def maxtol(key, precision):
+    """max-norm gate of `key` (tests/test_gpu_parity_fullsize.py)"""
+    if precision == "f16":
+        return MAXTOL_F16.get(key, 1e-3)
+    return MAXTOL[precision]
 
 
 def smplx_param_vector(rotmat, shape, expression):

@@ -976,7 +976,12 @@ def test_merged_qkv_launch_equals_the_two_launches(L, name, dt, tdt, tol, fold):
     _lib.check(L.mhmr_gemm16_ln(A.data_ptr(), C, Wv.data_ptr(), C, M, C, C, None if fold else bv.data_ptr(), None, vt2.data_ptr(), 0, Tp, H,
                                 _lib.EPI_VT, dt, 0, 0, 0, None, None, *((rs.data_ptr(), cv.data_ptr(), bv.data_ptr()) if fold else (None, None, None)),
                                 stream()), "vt")
-    assert torch.equal(qk, qk2) and torch.equal(vt, vt2)
+    # Q | K: the same epilogue in both forms -> bit-equal.  V: the merged launch computes it in the row-major orientation (weight = first
+    # MFMA operand, row statistics on the second operand's side), the V^T launch the other way round: without the fold the same fp32
+    # values; with it the two epilogues associate  rstd * acc + (-mean * rstd) * colsum + b'  differently -> the last fp32 bit, i.e. an
+    # occasional 16-bit ulp
+    assert torch.equal(qk, qk2)
+    assert torch.equal(vt, vt2) if not fold else (rel(vt, vt2) < 2e-5 and maxrel(vt, vt2) < (1e-3 if name == "f16" else 8e-3))
     lin = A.double() @ W.double().T
     want = (rs[:, 1:2].double() * (lin - rs[:, 0:1].double() * colsum.double()) + b.double()) if fold else lin + b.double()
     want[:, :C] *= _lib.ATTN_QSCALE

@@ -96,7 +96,7 @@ def test_full_size_forward_matches_reference_golden(name, precision, smplx_data,
                               "logit_gain_max": max(model._packed["logit_gain"]) if "logit_gain" in model._packed else None,
                               "backbone_rel_l2": e_bb, "max_vertex_error_mm": vmax_mm,
                               "worst_rel_l2": max(errs.values()), "rel_l2": errs, "finite": finite,
-                              "max_norm_tolerance": MAXTOL[tolkey], "worst_max_norm": max(merrs.values()), "max_norm": merrs,
+                              "max_norm_tolerance": {k: parity.maxtol(k, tolkey) for k in merrs}, "worst_max_norm": max(merrs.values()), "max_norm": merrs,
                               "network_sensitivity": sens,
                               "tokens": int(cfg["img_size"] // 14) ** 2 + 1, "persons": int(sum(cfg["persons"]))})
     print(f"\n[parity {name} {precision} -> {packed}] backbone {e_bb:.2e}; max vertex error {vmax_mm:.3f} mm; " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
@@ -115,9 +115,10 @@ def test_full_size_forward_matches_reference_golden(name, precision, smplx_data,
     for k, v in errs.items():
         assert v < TOL[tolkey], (name, precision, k, v, TOL[tolkey])
     assert e_bb < 2 * TOL[tolkey], e_bb                  # not a north-star output; informational bound
-    # ... and the max-norm gate on every key
+    # ... and the max-norm gate, per key (parity.maxtol: 1e-3, except the rotation matrices -- 2e-3: the 6D decode amplifies -- and the two
+    # pixel keys behind them, 1.5e-3)
     for k, v in merrs.items():
-        assert v < MAXTOL[tolkey], (name, "max-norm", k, v)
+        assert v < parity.maxtol(k, tolkey), (name, "max-norm", k, v, parity.maxtol(k, tolkey))
     if packed == "f16x3":
         assert e_bb < 1e-4 and max(errs.values()) < 3e-4, (e_bb, errs)      # the pair mode sits at fp32 accuracy, far inside the contract
 

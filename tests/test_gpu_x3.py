@@ -205,3 +205,30 @@ def test_x3_inference_mode_person_list_matches_reference_golden(name, smplx_data
             e = rel(got.numpy(), gold["h_" + k])
         assert e < 3e-4, (k, e)
     assert model(x.cuda(), K=K.cuda(), det_thresh=2.0) == []
+
+
+@pytest.mark.parametrize("strength", [0.45, 0.55, 0.65])
+def test_auto_never_leaves_a_ladder_point_outside_the_contract_on_plain_f16(strength, smplx_data, mean_params):
+    """The gate behind vit.logit_gain_limit (round 6): on the strength ladder between the seeded weights and `hostile_w` (full-depth ViT-L,
+    448^2, one image, 8 persons -- the probe of tools/auto_rule_probe.py, whose 896^2 / 1288^2 tables are committed under profiles/),
+    whatever `auto` resolves to must hold the 1e-3 contract against the CPU fp32 oracle on every key.  A rule that keeps a steep
+    checkpoint on plain f16 fails here; so does an f16x3 mode that stops being accurate."""
+    import copy
+    from oracle.multihmr_ref import OracleModel
+    S = 448
+    sd = copy.deepcopy(synthetic.make_state_dict("dinov2_vitl14", S, seed=31, mean_params=mean_params))
+    synthetic.make_hostile(sd, "weights", seed=31, strength=strength)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 3, S, S, generator=g)
+    K = synthetic.get_camera_K(S, 1)
+    idx = synthetic.make_pinned_idx(1, S // 14, 8, seed=3)
+    ref = OracleModel(sd, smplx_data, backbone="dinov2_vitl14", img_size=S).forward(x, idx=idx, K=K, is_training=True)
+    m = Model(backbone="dinov2_vitl14", img_size=S, smplx_data=smplx_data, mean_params=mean_params, precision="auto")
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    out = m(x.cuda(), idx=tuple(t.cuda() for t in idx), K=K.cuda(), is_training=True)
+    gain = max(m._packed["logit_gain"])
+    assert m.packed_precision == ("f16x3" if gain > vit.logit_gain_limit((S // 14) ** 2 + 1) else "f16")
+    errs = {k: rel(out[k].float().cpu().numpy(), ref[k].numpy()) for k in ("scores", "offset", "dist", "shape", "expression", "rotmat", "transl", "v3d", "j3d")}
+    print(f"\n[ladder {strength}] spread {gain:.2f} -> {m.packed_precision}: worst {max(errs.values()):.2e} ({max(errs, key=errs.get)})")
+    assert max(errs.values()) < (1e-3 if m.packed_precision == "f16" else 3e-4), (strength, gain, m.packed_precision, errs)

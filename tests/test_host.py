@@ -349,6 +349,10 @@ def test_logit_gain_statistic_and_the_auto_precision_rule():
         assert (gains[0] > vit.LOGIT_GAIN_LIMIT) == hostile, gains
         assert vit.resolve_precision(enc, "auto") == ("f16x3" if hostile else "f16")
         assert vit.resolve_precision(enc, "bf16") == "bf16" and vit.resolve_precision(enc, "fp16") == "f16"
+        # the limit follows the tokens per image above 896^2 (measured: plain f16 leaves the contract earlier on longer key sets)
+        assert vit.logit_gain_limit(None) == vit.logit_gain_limit(1025) == vit.logit_gain_limit(4097) == vit.LOGIT_GAIN_LIMIT == 4.0
+        assert 3.3 < vit.logit_gain_limit(8465) < 3.4 and vit.logit_gain_limit(10 ** 6) == 3.0
+        assert vit.resolve_precision(enc, "auto", tokens=8465) == ("f16x3" if hostile else "f16")
         # 'auto' choosing the slow mode FOR the caller is said out loud, once per pack, with the statistic and the way to force f16;
         # an explicit choice and the fast resolution are silent
         import warnings

@@ -46,7 +46,7 @@ def main():
     m = build("auto")
     m.load_state_dict(sd, strict=False)
     gains = vit.logit_gain(m.backbone.encoder)
-    print("block  logit spread (limit %.1f)" % vit.LOGIT_GAIN_LIMIT)
+    print("block  logit spread (limit %.1f at <= 4097 tokens per image, %.2f at 1288^2)" % (vit.LOGIT_GAIN_LIMIT, vit.logit_gain_limit(8465)))
     for i, gval in enumerate(gains):
         print("%5d  %8.2f %s" % (i, gval, "  <-- steep" if gval > vit.LOGIT_GAIN_LIMIT else ""))
     print("precision='auto' packs these weights as:", vit.resolve_precision(m.backbone.encoder, "auto"))
