@@ -506,10 +506,12 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
             if (fold) { g.x16 = d->xn; g.pstats = d->pstats; g.ldx16 = lo8 ? pit : 0; }
             masked(g);
             TRY(resid_linear(g));
-            AnyOrder ao_scope(ao);
             if (rowmap) {
-                // (with cst: + the patch rows' statistics for norm2, when the next linear consumes them)
+                // (with cst: + the patch rows' statistics for norm2, when the next linear consumes them.  THAT launch reads the block sums
+                // the GEMM in front of it has just written: an ordinary launch, not an any-order one -- session D of round 6 shipped it
+                // any-order for one GPU session and the full-size goldens caught the race: scores 2.5e-3, results differing run to run)
                 const ClsStats* cs = !cst ? nullptr : f2 ? &cs_produce_stats : &cs_produce;
+                AnyOrder ao_scope(ao && !(cst && f2));
                 TRY(mhmr_launch_cls_linear_fold((const char*)d->att + (size_t)cls_row * pit * esz, rowP, p_wc, p_kc, B, C, p_kc, p_akc, k.proj_b, k.ls1,
                                                 d->resid + (size_t)cls_row * C, rowC, 0, C, nullptr, d->H, Tp, 0, 1, dt, nullptr, 0, nullptr, nullptr,
                                                 fold ? (char*)d->xn + (size_t)cls_row * pit * esz : nullptr, rowP, s, cs));
@@ -549,11 +551,11 @@ int mhmr_vit_forward(const mhmr_vit_desc* d, const float* x, float* feat32, void
             }
             masked(g2);
             TRY(resid_linear(g2));
-            AnyOrder ao_scope2(ao);
             if (rowmap) {
-                // (with cst: + the patch rows' statistics for the NEXT block's norm1, when that block folds it)
+                // (with cst: + the patch rows' statistics for the NEXT block's norm1, when that block folds it: an ordinary launch then)
                 const bool next_f1 = l + 1 < d->L && fold && (d->blocks[l + 1].flags & 1);
                 const ClsStats* cs = !cst ? nullptr : next_f1 ? &cs_produce_stats : &cs_produce;
+                AnyOrder ao_scope2(ao && !(cst && next_f1));
                 TRY(mhmr_launch_cls_linear_fold((const char*)d->hid + (size_t)cls_row * 4 * C * esz, 4 * rowC, k.fc2_w, 4 * C, B, C, 4 * C, 0, k.fc2_b,
                                                 k.ls2, d->resid + (size_t)cls_row * C, rowC, 0, C, nullptr, d->H, Tp, 0, 1, dt, nullptr, 0, nullptr,
                                                 nullptr, fold ? (char*)d->xn + (size_t)cls_row * pit * esz : nullptr, rowP, s, cs));

@@ -533,6 +533,48 @@ __global__ __launch_bounds__(256) void lbs_pose4_kernel(const mhmr_lbs_consts c,
     if (w == 0) POSE_STAMP(5);
     // ---------------- phase B: the kinematic chain, one tree level at a time, one lane per (joint, element) ----------------
     const int maxdepth = S.sMaxDepth;
+    // The timeline (tools/lbs_pose_timeline.py, profiles/r06_session_d*.txt) put 4.3 of the kernel's 8.8 us HERE: per level the loop below is
+    // three DEPENDENT rounds of LDS reads (level list -> parent -> transforms) and a barrier, 0.43 us a level.  Common case -- at most 16
+    // levels of at most 21 joints (SMPL-X: 10 levels, <= 13 joints): a lane's task at every level is the same (slot, element), so its
+    // joint and parent of ALL levels come into registers first (16 independent reads), and a level is ONE round of reads, FMAs, a store.
+    bool fastpath = maxdepth < 16;
+    for (int level = 0; level <= maxdepth && level < 16; ++level) fastpath = fastpath && S.sCnt[level] * 12 <= 256;
+    if (fastpath) {
+        const int slot = tid / 12, e = tid - slot * 12;
+        int task[16];                          // joint | parent << 8 (parent 0xff = a root), -1 = no task at that level
+#pragma unroll
+        for (int level = 0; level < 16; ++level) {
+            task[level] = -1;
+            if (level <= maxdepth && slot < S.sCnt[level]) {
+                const int jj = S.sList[level][slot];
+                task[level] = jj | ((sPar[jj] & 0xff) << 8);
+            }
+        }
+#pragma unroll
+        for (int level = 0; level < 16; ++level) {
+            if (level <= maxdepth) {
+                if (task[level] >= 0) {
+                    const int jj = task[level] & 0xff, pa = task[level] >> 8;
+                    if (pa == 0xff) {
+                        if (e < 9) sRw[jj][e] = sR[jj][e];
+                        else sTw[jj][e - 9] = sJ[jj][e - 9];
+                    } else if (e < 9) {
+                        const int i = e / 3, k = e - i * 3;
+                        const float* a = &sRw[pa][0];
+                        const float* b = &sR[jj][0];
+                        sRw[jj][e] = a[i * 3] * b[k] + a[i * 3 + 1] * b[3 + k] + a[i * 3 + 2] * b[6 + k];
+                    } else {
+                        const int i = e - 9;
+                        const float* a = &sRw[pa][0];
+                        const float rel[3] = {sJ[jj][0] - sJ[pa][0], sJ[jj][1] - sJ[pa][1], sJ[jj][2] - sJ[pa][2]};
+                        const float tv = a[i * 3] * rel[0] + a[i * 3 + 1] * rel[1] + a[i * 3 + 2] * rel[2];
+                        sTw[jj][i] = tv + sTw[pa][i];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    } else
     for (int level = 0; level <= maxdepth; ++level) {
         const int n12 = S.sCnt[level] * 12;
         for (int t = tid; t < n12; t += 256) {

@@ -102,9 +102,11 @@ int mhmr_cu_count();
 // inputs were complete before the PREVIOUS launch started and whose outputs nothing touches until the next ordinary launch (which waits
 // for everything before it): the V projection behind the Q | K projection, the class-row linears behind the big GEMM of the same
 // linear.  MEASURED (round 6, tools/ubench/anyorder.hip + a kernel trace of the forward, profiles/r06_session_a.txt / _b.txt): on gfx950 /
-// ROCm 7.2 such a kernel still starts only after the kernel in front of it has finished -- no overlap (hip_ext.h says as much: "not
-// supported on GFX9xx") -- but 0.5 us earlier, and the headline step is 0.1-0.8 % faster in six of six interleaved A/B pairs.  So: on by
-// default for what it is, a cheaper boundary.  MHMR_ANYORDER=0 switches it off (A/B measurements); never set while a stream is being captured.
+// ROCm 7.2 such a kernel starts about when the kernel in front of it ends -- a persistent GEMM holds every CU until then, so nothing
+// overlaps for long (the trace shows ~8 boundaries per forward where the next kernel starts 0.1-0.2 us BEFORE its predecessor's end;
+// hip_ext.h calls the flag "not supported on GFX9xx") -- but the ordering IS relaxed: a class-row launch that also read the block sums
+// of the GEMM in front of it, launched this way by mistake for one session, returned wrong, run-to-run different statistics.  The
+// headline step is 0.1-0.8 % faster in six of six interleaved A/B pairs.  On by default, ONLY for launches independent of their predecessor.  MHMR_ANYORDER=0 switches it off (A/B measurements); never set while a stream is being captured.
 extern thread_local int g_mhmr_anyorder;
 #include <hip/hip_ext.h>
 template <typename F, typename... Args>

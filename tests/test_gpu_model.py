@@ -390,14 +390,14 @@ def test_row_statistics_inside_the_class_row_launches(name, smplx_data, mean_par
     class rows get block sums of their own -- no ln_stats launch.  Against the separate launches (MHMR_CLS_STATS=0, read per call): the
     patch rows' statistics are the same arithmetic (bit-equal), the class rows' variance is E[x^2] - mean^2 from sixteen-column block sums
     instead of the centred form, so the features agree to the 16-bit noise level, not to the last bit; run to run it is bit-reproducible."""
-    cfg = dict(make_golden.CASES[name], batch=40, persons=None)      # two image blocks of 20 at 224^2: not tiny -> token-row map + class-row kernel
+    cfg = dict(make_golden.CASES[name], batch=48, persons=None)      # two image blocks of 24 at 224^2: not tiny -> token-row map + class-row kernel
     model = build(cfg, smplx_data, mean_params, "f16")
     x, _, _ = make_golden.case_inputs(cfg)
     x = x.cuda()
     from multi_hmr_amd import vit
     z1 = model.backbone_features(x).clone()
     P = model._packed
-    assert P["fold"] and vit.row_map(P, 40 // model._nsplit(40)) and "cls_pstats" in model._workspace(P, 40)["parts"][0]["bufs"]
+    assert P["fold"] and vit.row_map(P, 48 // model._nsplit(48)) and "cls_pstats" in model._workspace(P, 48)["parts"][0]["bufs"]
     z1b = model.backbone_features(x).clone()
     assert torch.equal(z1, z1b)
     monkeypatch.setenv("MHMR_CLS_STATS", "0")
