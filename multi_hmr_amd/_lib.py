@@ -125,7 +125,8 @@ class HphDesc(C.Structure):
 
 class LbsConsts(C.Structure):
     _fields_ = ([(n, _i) for n in ("V", "Vp", "Vl", "Kb", "nb", "Kinf", "center_joint")] +
-                [(n, _vp) for n in ("basis16", "vtemp", "J0", "JS", "parents", "skin_idx", "skin_w", "skin16", "xbary")])
+                [(n, _vp) for n in ("basis16", "vtemp", "J0", "JS", "parents", "skin_idx", "skin_w", "skin16", "xbary", "pose_tasks")] +
+                [("pose_levels", _i)])
 
 
 _SIGS = {

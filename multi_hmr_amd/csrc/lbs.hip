@@ -409,6 +409,12 @@ __global__ __launch_bounds__(256) void lbs_pose4_kernel(const mhmr_lbs_consts c,
         return;
     }
     const int ncoef = c.nb + 10;
+    // the kinematic tree's level schedule from the host (mhmr_lbs_consts::pose_tasks): this lane's task at every level, requested with
+    // everything else of phase A (one round trip); without it wave 3 derives the schedule from `parents` (1.5 us more, the timeline says)
+    const bool host_tasks = c.pose_tasks != nullptr && c.pose_levels >= 1 && c.pose_levels <= 16;
+    int task[16];
+#pragma unroll
+    for (int level = 0; level < 16; ++level) task[level] = (host_tasks && level < c.pose_levels) ? c.pose_tasks[level * 256 + tid] : -1;
     // ---------------- phase A: four roles ----------------
     if (w == 0) {
         if (j < NJ) {
@@ -469,8 +475,17 @@ __global__ __launch_bounds__(256) void lbs_pose4_kernel(const mhmr_lbs_consts c,
         }
     } else if (w == 2) {
         if (j == 63) {
-            // root orientation (roma.rotvec_to_rotmat), translation (inverse_perspective_projection) -- as in lbs_pose_person
-            const float* rv = rotvec + (size_t)p * 53 * 3;
+            // root orientation (roma.rotvec_to_rotmat), translation (inverse_perspective_projection) -- as in lbs_pose_person.  The
+            // image index first and the camera matrix right behind it: the second of the two dependent round trips then runs under the
+            // sin / cos below instead of behind it
+            const int db = det_b[p];
+            const float* rvp = rotvec + (size_t)p * 53 * 3;
+            const float rv[3] = {rvp[0], rvp[1], rvp[2]};
+            const float lx = loc[2 * p], ly = loc[2 * p + 1], d = dist[p];
+            const float* Kg = Kmat + (size_t)db * 9;
+            float Kp[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) Kp[e] = Kg[e];
             const float th = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
             const float den = fmaxf(th, 1e-6f);
             const float kx = rv[0] / den, ky = rv[1] / den, kz = rv[2] / den;
@@ -481,10 +496,8 @@ __global__ __launch_bounds__(256) void lbs_pose4_kernel(const mhmr_lbs_consts c,
             const float xyc = kx * ky * omc, xzc = kx * kz * omc, yzc = ky * kz * omc;
             const float xxc = kx * kx * omc, yyc = ky * ky * omc, zzc = kz * kz * omc;
             const float R0[9] = {1.f - yyc - zzc, xyc - zs, xzc + ys, xyc + zs, 1.f - xxc - zzc, -xs + yzc, xzc - ys, xs + yzc, 1.f - xxc - yyc};
-            const float* Kp = Kmat + (size_t)det_b[p] * 9;
             float Ki[9];
             inv3x3(Kp, Ki);
-            const float lx = loc[2 * p], ly = loc[2 * p + 1], d = dist[p];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const float tr = (Ki[a * 3] * lx + Ki[a * 3 + 1] * ly + Ki[a * 3 + 2] * 1.0f) * d;
@@ -508,6 +521,8 @@ __global__ __launch_bounds__(256) void lbs_pose4_kernel(const mhmr_lbs_consts c,
         if (j == 63) {
             for (int comp = 0; comp < 12; ++comp) sA[comp][63] = 0.f;
         }
+    } else if (host_tasks) {
+        if (j == 0) S.sMaxDepth = c.pose_levels - 1;          // (the schedule came from the host: nothing to derive)
     } else {
         // topology: parents, depth of every joint, and per tree level the list of its joints (in joint order)
         if (j < NJ) sPar[j] = c.parents[j];
@@ -537,17 +552,20 @@ __global__ __launch_bounds__(256) void lbs_pose4_kernel(const mhmr_lbs_consts c,
     // three DEPENDENT rounds of LDS reads (level list -> parent -> transforms) and a barrier, 0.43 us a level.  Common case -- at most 16
     // levels of at most 21 joints (SMPL-X: 10 levels, <= 13 joints): a lane's task at every level is the same (slot, element), so its
     // joint and parent of ALL levels come into registers first (16 independent reads), and a level is ONE round of reads, FMAs, a store.
-    bool fastpath = maxdepth < 16;
-    for (int level = 0; level <= maxdepth && level < 16; ++level) fastpath = fastpath && S.sCnt[level] * 12 <= 256;
+    bool fastpath = host_tasks || maxdepth < 16;
+    if (!host_tasks)
+        for (int level = 0; level <= maxdepth && level < 16; ++level) fastpath = fastpath && S.sCnt[level] * 12 <= 256;
     if (fastpath) {
         const int slot = tid / 12, e = tid - slot * 12;
-        int task[16];                          // joint | parent << 8 (parent 0xff = a root), -1 = no task at that level
+        // task[level]: joint | parent << 8 (parent 0xff = a root), -1 = no task at that level
+        if (!host_tasks) {
 #pragma unroll
-        for (int level = 0; level < 16; ++level) {
-            task[level] = -1;
-            if (level <= maxdepth && slot < S.sCnt[level]) {
-                const int jj = S.sList[level][slot];
-                task[level] = jj | ((sPar[jj] & 0xff) << 8);
+            for (int level = 0; level < 16; ++level) {
+                task[level] = -1;
+                if (level <= maxdepth && slot < S.sCnt[level]) {
+                    const int jj = S.sList[level][slot];
+                    task[level] = jj | ((sPar[jj] & 0xff) << 8);
+                }
             }
         }
 #pragma unroll

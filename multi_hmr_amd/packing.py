@@ -154,6 +154,8 @@ def pack_smplx(data: dict, num_betas: int, device, person_center_idx: int = 15) 
     return {
         "V": V, "Vp": Vp, "Vl": Vl, "Kb": Kb, "nb": num_betas, "Kinf": Kinf, "center_joint": person_center_idx,
         "basis16": t(basis16, torch.float16), "vtemp": t(vtemp, torch.float32), "J0": t(J0, torch.float32), "JS": t(JS.reshape(55 * 3, ncoef), torch.float32),
+        "pose_tasks": (lambda tk: t(tk[0], torch.int32) if tk[0] is not None else None)(pose_level_tasks(parents)),
+        "pose_levels": pose_level_tasks(parents)[1],
         "parents": t(parents.astype(np.int32), torch.int32), "skin_idx": t(skin_idx, torch.int32), "skin_w": t(skin_w, torch.float32),
         "skin16": t(skin16, torch.float16),
         "xbary": t(xbary, torch.float32), "extra_vid": t(picked, torch.int32), "lmk_vidx": t(lmk_vidx, torch.int32),
@@ -168,4 +170,32 @@ def lbs_consts_struct(p: dict) -> "_lib.LbsConsts":
         setattr(c, k, int(p[k]))
     for k in ("basis16", "vtemp", "J0", "JS", "parents", "skin_idx", "skin_w", "skin16", "xbary"):
         setattr(c, k, p[k].data_ptr())
+    # the kinematic tree's level schedule for the pose kernel (include/mhmr.h: pose_tasks), when the tree fits its fast path
+    c.pose_tasks = p["pose_tasks"].data_ptr() if p.get("pose_tasks") is not None else None
+    c.pose_levels = int(p.get("pose_levels", 0))
     return c
+
+
+def pose_level_tasks(parents) -> "tuple[np.ndarray | None, int]":
+    """parents [J] (root: -1) -> (int32 [16, 256] level schedule, number of levels), or (None, 0) when the tree does not fit the pose
+    kernel's fast path (more than 16 levels or more than 21 joints on one level).  Lane 12 s + e of level L works on element e of the
+    s-th joint (in joint order) of that level: value = joint | parent << 8, parent 0xff for a root; -1 = idle."""
+    parents = [int(v) for v in parents]
+    depth = []
+    for j in range(len(parents)):
+        d, a = 0, parents[j]
+        while a >= 0:
+            d, a = d + 1, parents[a]
+        depth.append(d)
+    nlev = max(depth) + 1
+    if nlev > 16 or len(parents) > 255:
+        return None, 0
+    tasks = np.full((16, 256), -1, dtype=np.int32)
+    for L in range(nlev):
+        joints = [j for j in range(len(parents)) if depth[j] == L]
+        if len(joints) * 12 > 256:
+            return None, 0
+        for s, j in enumerate(joints):
+            pa = parents[j] if parents[j] >= 0 else 0xff
+            tasks[L, 12 * s:12 * s + 12] = j | (pa << 8)
+    return tasks, nlev
