@@ -399,10 +399,10 @@ typedef struct {
                              j = 8 * block + lane-local index: the B operand of the skinning GEMM            */
     const float* xbary;   /* [72*3]            corner weights of the extra joints: (1, 0, 0) for joints 55..75 (vertices picked by id),
                              lmk_bary_coords for 76..126 (faces[lmk_faces_idx] are the corners)                 */
-    /* (105) The kinematic chain's step schedule, or NULL (then the pose kernel derives a level schedule from `parents` at run time).  The
-     * joints of a tree level, in joint order, in chunks of five = one STEP of one wave: int32 [24][64], pose_tasks[step][lane] = joint |
-     * parent << 8 (parent 0xff = a root) for lane = 12 * (position in the chunk) + element (0..8 of the rotation, 9..11 of the
-     * translation), -1 for idle lanes; steps in level order; pose_levels = number of steps (SMPL-X: 14).  Only for trees of <= 24 steps. */
+    /* (105) The kinematic tree's level schedule, or NULL (then the pose kernel derives it from `parents` at run time).  int32 [16][256]:
+     * pose_tasks[level][lane] = joint | parent << 8 (parent 0xff = a root) for lane = 12 * (position of the joint in its level's list, in
+     * joint order) + element (0..8 of the rotation, 9..11 of the translation), -1 where the level has no such lane; pose_levels = number of
+     * tree levels.  Only for trees of at most 16 levels with at most 21 joints per level (SMPL-X: 10 levels, <= 13 joints). */
     const int* pose_tasks;
     int pose_levels;
 } mhmr_lbs_consts;

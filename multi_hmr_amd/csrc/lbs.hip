@@ -409,12 +409,12 @@ __global__ __launch_bounds__(256) void lbs_pose4_kernel(const mhmr_lbs_consts c,
         return;
     }
     const int ncoef = c.nb + 10;
-    // the kinematic chain's step schedule from the host (mhmr_lbs_consts::pose_tasks): wave 0's task at every step, requested with
-    // everything else of phase A (one round trip); without it wave 3 derives a level schedule from `parents` (1.5 us more, the timeline says)
-    const bool host_tasks = c.pose_tasks != nullptr && c.pose_levels >= 1 && c.pose_levels <= 24;
-    int task[24];
+    // the kinematic tree's level schedule from the host (mhmr_lbs_consts::pose_tasks): this lane's task at every level, requested with
+    // everything else of phase A (one round trip); without it wave 3 derives the schedule from `parents` (1.5 us more, the timeline says)
+    const bool host_tasks = c.pose_tasks != nullptr && c.pose_levels >= 1 && c.pose_levels <= 16;
+    int task[16];
 #pragma unroll
-    for (int st = 0; st < 24; ++st) task[st] = (w == 0 && host_tasks && st < c.pose_levels) ? c.pose_tasks[st * 64 + j] : -1;
+    for (int level = 0; level < 16; ++level) task[level] = (host_tasks && level < c.pose_levels) ? c.pose_tasks[level * 256 + tid] : -1;
     // ---------------- phase A: four roles ----------------
     if (w == 0) {
         if (j < NJ) {
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void lbs_pose4_kernel(const mhmr_lbs_consts c,
             for (int comp = 0; comp < 12; ++comp) sA[comp][63] = 0.f;
         }
     } else if (host_tasks) {
-        if (j == 0) S.sMaxDepth = 0;                          // (the schedule came from the host: nothing to derive)
+        if (j == 0) S.sMaxDepth = c.pose_levels - 1;          // (the schedule came from the host: nothing to derive)
     } else {
         // topology: parents, depth of every joint, and per tree level the list of its joints (in joint order)
         if (j < NJ) sPar[j] = c.parents[j];
@@ -552,58 +552,27 @@ __global__ __launch_bounds__(256) void lbs_pose4_kernel(const mhmr_lbs_consts c,
     // three DEPENDENT rounds of LDS reads (level list -> parent -> transforms) and a barrier, 0.43 us a level.  Common case -- at most 16
     // levels of at most 21 joints (SMPL-X: 10 levels, <= 13 joints): a lane's task at every level is the same (slot, element), so its
     // joint and parent of ALL levels come into registers first (16 independent reads), and a level is ONE round of reads, FMAs, a store.
-    // With the host's STEP schedule the whole chain runs on wave 0 alone -- five joints (60 lanes) per step, a level of ten joints = two
-    // steps, 14 steps for SMPL-X -- with nothing between steps but the wave's own LDS ordering: a workgroup barrier per level was most of
-    // what a level cost (timeline: 2.8 us for 11 levels with the level schedule in registers; profiles/r06_session_f*.txt).
-    if (host_tasks) {
-        if (w == 0) {
-            const int slot = j / 12, e = j - slot * 12;
-#pragma unroll
-            for (int st = 0; st < 24; ++st) {
-                if (st < c.pose_levels) {
-                    if (task[st] >= 0) {
-                        const int jj = task[st] & 0xff, pa = task[st] >> 8;
-                        if (pa == 0xff) {
-                            if (e < 9) sRw[jj][e] = sR[jj][e];
-                            else sTw[jj][e - 9] = sJ[jj][e - 9];
-                        } else if (e < 9) {
-                            const int i = e / 3, k = e - i * 3;
-                            const float* a = &sRw[pa][0];
-                            const float* b = &sR[jj][0];
-                            sRw[jj][e] = a[i * 3] * b[k] + a[i * 3 + 1] * b[3 + k] + a[i * 3 + 2] * b[6 + k];
-                        } else {
-                            const int i = e - 9;
-                            const float* a = &sRw[pa][0];
-                            const float rel[3] = {sJ[jj][0] - sJ[pa][0], sJ[jj][1] - sJ[pa][1], sJ[jj][2] - sJ[pa][2]};
-                            const float tv = a[i * 3] * rel[0] + a[i * 3 + 1] * rel[1] + a[i * 3 + 2] * rel[2];
-                            sTw[jj][i] = tv + sTw[pa][i];
-                        }
-                    }
-                    LBS_WAVE_SYNC();
-                }
-            }
-        }
-        __syncthreads();
-    } else {
-    bool fastpath = maxdepth < 16;
-    for (int level = 0; level <= maxdepth && level < 16; ++level) fastpath = fastpath && S.sCnt[level] * 12 <= 256;
+    bool fastpath = host_tasks || maxdepth < 16;
+    if (!host_tasks)
+        for (int level = 0; level <= maxdepth && level < 16; ++level) fastpath = fastpath && S.sCnt[level] * 12 <= 256;
     if (fastpath) {
         const int slot = tid / 12, e = tid - slot * 12;
-        // ltask[level]: joint | parent << 8 (parent 0xff = a root), -1 = no task at that level
-        int ltask[16];
+        // task[level]: joint | parent << 8 (parent 0xff = a root), -1 = no task at that level
+        if (!host_tasks) {
 #pragma unroll
-        for (int level = 0; level < 16; ++level) {
-            ltask[level] = -1;
-            if (level <= maxdepth && slot < S.sCnt[level]) {
-                const int jj = S.sList[level][slot];
-                ltask[level] = jj | ((sPar[jj] & 0xff) << 8);
+            for (int level = 0; level < 16; ++level) {
+                task[level] = -1;
+                if (level <= maxdepth && slot < S.sCnt[level]) {
+                    const int jj = S.sList[level][slot];
+                    task[level] = jj | ((sPar[jj] & 0xff) << 8);
+                }
             }
         }
 #pragma unroll
         for (int level = 0; level < 16; ++level) {
             if (level <= maxdepth) {
-                if (ltask[level] >= 0) {
-                    const int jj = ltask[level] & 0xff, pa = ltask[level] >> 8;
+                if (task[level] >= 0) {
+                    const int jj = task[level] & 0xff, pa = task[level] >> 8;
                     if (pa == 0xff) {
                         if (e < 9) sRw[jj][e] = sR[jj][e];
                         else sTw[jj][e - 9] = sJ[jj][e - 9];
@@ -647,7 +616,6 @@ __global__ __launch_bounds__(256) void lbs_pose4_kernel(const mhmr_lbs_consts c,
             }
         }
         __syncthreads();
-    }
     }
     // ---------------- phase C: recentring, then the per-joint read-outs ----------------
     if (w == 0) POSE_STAMP(6);

@@ -177,9 +177,9 @@ def lbs_consts_struct(p: dict) -> "_lib.LbsConsts":
 
 
 def pose_level_tasks(parents) -> "tuple[np.ndarray | None, int]":
-    """parents [J] (root: -1) -> (int32 [24, 64] step schedule of the kinematic chain, number of steps), or (None, 0) when the tree needs more
-    than 24 steps.  A step = up to five joints of ONE tree level (in joint order), twelve lanes each: lane 12 s + e works on element e of
-    the chunk's s-th joint: value = joint | parent << 8, parent 0xff for a root; -1 = idle.  Steps run in level order (csrc/lbs.hip)."""
+    """parents [J] (root: -1) -> (int32 [16, 256] level schedule, number of levels), or (None, 0) when the tree does not fit the pose
+    kernel's fast path (more than 16 levels or more than 21 joints on one level).  Lane 12 s + e of level L works on element e of the
+    s-th joint (in joint order) of that level: value = joint | parent << 8, parent 0xff for a root; -1 = idle."""
     parents = [int(v) for v in parents]
     depth = []
     for j in range(len(parents)):
@@ -188,19 +188,14 @@ def pose_level_tasks(parents) -> "tuple[np.ndarray | None, int]":
             d, a = d + 1, parents[a]
         depth.append(d)
     nlev = max(depth) + 1
-    if len(parents) > 255:
+    if nlev > 16 or len(parents) > 255:
         return None, 0
-    steps = []
+    tasks = np.full((16, 256), -1, dtype=np.int32)
     for L in range(nlev):
         joints = [j for j in range(len(parents)) if depth[j] == L]
-        for c0 in range(0, len(joints), 5):
-            row = np.full(64, -1, dtype=np.int32)
-            for s, j in enumerate(joints[c0:c0 + 5]):
-                pa = parents[j] if parents[j] >= 0 else 0xff
-                row[12 * s:12 * s + 12] = j | (pa << 8)
-            steps.append(row)
-    if len(steps) > 24:
-        return None, 0
-    tasks = np.full((24, 64), -1, dtype=np.int32)
-    tasks[:len(steps)] = np.stack(steps)
-    return tasks, len(steps)
+        if len(joints) * 12 > 256:
+            return None, 0
+        for s, j in enumerate(joints):
+            pa = parents[j] if parents[j] >= 0 else 0xff
+            tasks[L, 12 * s:12 * s + 12] = j | (pa << 8)
+    return tasks, nlev

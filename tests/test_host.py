@@ -427,27 +427,28 @@ def test_output_block_layout_and_the_graph_wrapper_without_a_gpu(smplx_data, mea
 
 
 def test_pose_level_schedule_of_the_kinematic_tree(smplx_data):
-    """packing.pose_level_tasks (mhmr_lbs_consts::pose_tasks): the chain's STEP schedule -- every joint exactly once, twelve lanes, with its
-    parent, in a step that comes after its parent's step; a step holds joints of ONE level, in joint order, at most five; trees that need
-    more than 24 steps return None."""
+    """packing.pose_level_tasks (mhmr_lbs_consts::pose_tasks): every joint appears exactly once, on the level of its depth, with its parent,
+    twelve lanes per joint; a level's joints are in joint order; trees that do not fit the pose kernel's fast path return None."""
     par = np.asarray(smplx_data["kintree_table"])[0].astype(np.int64).copy()
     par[0] = -1
-    tasks, nsteps = packing.pose_level_tasks(par)
-    assert tasks.shape == (24, 64) and tasks.dtype == np.int32 and nsteps == 14 and (tasks[nsteps:] == -1).all()
-    depth = lambda j: 0 if par[j] < 0 else 1 + depth(par[j])
-    step_of, order = {}, []
-    for s in range(nsteps):
-        row = tasks[s]
+    tasks, nlev = packing.pose_level_tasks(par)
+    assert tasks.shape == (16, 256) and tasks.dtype == np.int32 and nlev == 11 and (tasks[nlev:] == -1).all()
+    seen = {}
+    for L in range(nlev):
+        row = tasks[L]
         live = row[row >= 0]
-        assert 12 <= live.size <= 60 and live.size % 12 == 0 and (row[live.size:] == -1).all()
+        assert live.size % 12 == 0 and (row[live.size:] == -1).all()
         joints = [int(v) & 0xff for v in live[::12]]
-        assert joints == sorted(joints) and len({depth(j) for j in joints}) == 1
-        for k, j in enumerate(joints):
-            assert (row[12 * k:12 * k + 12] == row[12 * k]).all()
-            assert (int(row[12 * k]) >> 8) == (0xff if par[j] < 0 else par[j])
-            assert j not in step_of and (par[j] < 0 or step_of[par[j]] < s)
-            step_of[j] = s
-        order.append(depth(joints[0]))
-    assert sorted(step_of) == list(range(55)) and order == sorted(order)
-    assert packing.pose_level_tasks(np.arange(-1, 30))[0] is None                    # a chain of 31 joints: 31 steps
-    assert packing.pose_level_tasks(np.array([-1] + [0] * 30))[1] == 7               # a star: 1 + 30 / 5 steps
+        assert joints == sorted(joints)
+        for s, j in enumerate(joints):
+            assert (row[12 * s:12 * s + 12] == row[12 * s]).all()
+            pa = int(row[12 * s]) >> 8
+            assert pa == (0xff if par[j] < 0 else par[j])
+            d, a = 0, par[j]
+            while a >= 0:
+                d, a = d + 1, par[a]
+            assert d == L
+            seen[j] = seen.get(j, 0) + 1
+    assert sorted(seen) == list(range(55)) and set(seen.values()) == {1}
+    assert packing.pose_level_tasks(np.arange(-1, 20))[0] is None                    # a chain of 21 joints: 21 levels
+    assert packing.pose_level_tasks(np.array([-1] + [0] * 30))[0] is None            # a star: 30 joints on one level
