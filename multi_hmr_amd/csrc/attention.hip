@@ -371,32 +371,35 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void attn_kernel(
 
 // The gated textbook pass behind a MODE 3 form (round 6).  Rounds 2-5 launched the textbook kernel over the WHOLE grid and let every
 // workgroup read its four flags and return: 16 896 workgroups at the headline, 9-11 us per launch for nothing (nothing is ever flagged on
-// real or random data), 24 times per forward.  Here a workgroup scans 256 workgroups' flags with one 16-byte load per thread -- the grid is
-// ceil(nwg / 256) workgroups: 66 at the headline, 3 for a batch of one -- and recomputes the flagged ones of its slice one after the other
-// (the rare path trades parallelism for the common path's launch).
+// real or random data), 24 times per forward.  Here a workgroup looks at the flags of FALLBACK_SLICE = 16 workgroups (one 16-byte load in each
+// of 16 lanes) -- the grid is ceil(nwg / 16) workgroups: 1 056 at the headline = ONE round of the chip's 1 024 workgroup slots instead of
+// sixteen and a half, 34 for a batch of one -- and recomputes the flagged ones of its slice one after the other.  Worst case (steep weights
+// with the precision forced to plain f16: every workgroup flagged): 16 recomputations in a row on every slot = what the full grid took.
+// (First form of the round: slices of 256, 66 workgroups -- 1 us less in the common case, 16 x the time when everything is flagged:
+// 170 ms against 19 for the forced-f16 hostile-weights forward, profiles/r06_final_validation_summary_lib_909c1f76.txt.)
+constexpr int FALLBACK_SLICE = 16;
 template <int DT>
 __global__ __launch_bounds__(256, 4) void attn_fallback_kernel(const void* __restrict__ qk_, const void* __restrict__ vt_, void* __restrict__ out_,
                                                                int T, int Tp, int C, int H, int nqt, float limit, int* __restrict__ flags,
                                                                int ldo, int o8, int nwg) {
-    __shared__ unsigned long long smask[4];
-    const int tid = threadIdx.x, wg = blockIdx.x * 256 + tid;
-    int any = 0;
-    if (wg < nwg) {
-        const int4 f = *(const int4*)(flags + 4 * wg);        // (one flag per wave of the MODE 3 workgroup, written unconditionally)
-        any = (f.x | f.y | f.z | f.w) != 0;
-    }
-    const unsigned long long m = __ballot(any);
-    if ((tid & 63) == 0) smask[tid >> 6] = m;
-    __syncthreads();
-    if ((smask[0] | smask[1] | smask[2] | smask[3]) == 0ull) return;
-    for (int q = 0; q < 4; ++q) {
-        unsigned long long mm = smask[q];
-        while (mm) {
-            const int bit = __builtin_ctzll(mm);
-            mm &= mm - 1;
-            attn_body<DT, 4, 2, 1>(qk_, vt_, out_, T, Tp, C, H, nqt, limit, nullptr, ldo, o8, blockIdx.x * 256 + 64 * q + bit);
-            __syncthreads();                                  // the K / V ring of the next flagged workgroup re-uses this one's LDS
+    __shared__ unsigned int smask;
+    const int tid = threadIdx.x, wg = blockIdx.x * FALLBACK_SLICE + tid;
+    if (tid < 64) {
+        int any = 0;
+        if (tid < FALLBACK_SLICE && wg < nwg) {
+            const int4 f = *(const int4*)(flags + 4 * wg);    // (one flag per wave of the MODE 3 workgroup, written unconditionally)
+            any = (f.x | f.y | f.z | f.w) != 0;
         }
+        const unsigned long long m = __ballot(any);
+        if (tid == 0) smask = (unsigned int)m;
+    }
+    __syncthreads();
+    unsigned int mm = smask;
+    while (mm) {
+        const int bit = __builtin_ctz(mm);
+        mm &= mm - 1;
+        attn_body<DT, 4, 2, 1>(qk_, vt_, out_, T, Tp, C, H, nqt, limit, nullptr, ldo, o8, blockIdx.x * FALLBACK_SLICE + bit);
+        __syncthreads();                                      // the K / V ring of the next flagged workgroup re-uses this one's LDS
     }
 }
 
@@ -1004,7 +1007,7 @@ int launch_attn_fallback(const void* qk, const void* vt, void* out, int B, int T
                          hipStream_t s, int ldo = 0, int o8 = 0) {
     if (ldo <= 0) ldo = C;
     const int nqt = (Tp + 127) / 128, nwg = nqt * H * B;
-    const int grid = (nwg + 255) / 256;
+    const int grid = (nwg + FALLBACK_SLICE - 1) / FALLBACK_SLICE;
     const size_t lds = 2 * 2 * KV_TILE_BYTES + 4 * 256;
     if (dtype == MHMR_DT_F16)
         hipLaunchKernelGGL((attn_fallback_kernel<MHMR_DT_F16>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags, ldo, o8, nwg);

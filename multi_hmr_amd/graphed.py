@@ -47,8 +47,15 @@ class GraphedForward:
             # eager warm-up: packs the weights, allocates the workspace, sets the kernels' per-device attributes -- none of which may
             # happen under stream capture
             # (two calls at least: the first call of a model sizes the person capacity from the count and, on an empty image, never reaches the heads)
+            # (the warm-up runs on a blank image: the person capacity it leaves for this batch size would be the minimum -- an eager
+            # forward of a real batch right behind it would overflow and run its heads twice; round-5 advisor finding.  Put back what was there.)
+            cap_before = model._person_cap.get(self.batch)
             for _ in range(max(int(warmup), 2)):
                 model(self.x, K=self.K, det_thresh=self.det_thresh, nms_kernel_size=self.nms_kernel_size)
+            if cap_before is None:
+                model._person_cap.pop(self.batch, None)
+            else:
+                model._person_cap[self.batch] = cap_before
             P, ws, _ = model._prepare(self.x)
             self._pack, self._ws = P, ws           # the graph holds raw pointers into both: keep them alive past a repack()
             torch.cuda.synchronize(dev)

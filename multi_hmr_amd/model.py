@@ -443,9 +443,10 @@ class Model(nn.Module):
 
     def backbone_features(self, x):
         """[B,3,S,S] -> [B,N,C] fp32 patch features (reference blocks/dinov2.py:16-26), as a view of the workspace."""
-        P, ws, stream = self._prepare(x)
-        self._run_backbone(P, ws, x)
-        return ws["feat32"].view(x.shape[0], P["N"], P["C"])
+        with self._lock:                      # (workspaces belong to the instance: same lock as forward(); round-5 advisor finding)
+            P, ws, stream = self._prepare(x)
+            self._run_backbone(P, ws, x)
+            return ws["feat32"].view(x.shape[0], P["N"], P["C"])
 
     def _prepare(self, x):
         if self.camera_embedding is None:
