@@ -52,7 +52,9 @@ def main():
         N_img = T - 1
         shapes = [("qk   (EPI_OP16_QK)", 2 * C, C, _lib.EPI_OP16_QK, 0), ("v    (EPI_VT)", C, C, _lib.EPI_VT, 0), ("v+lo (EPI_VT)", C, C, _lib.EPI_VT, 1),
                   ("proj (EPI_RESID)", C, C, _lib.EPI_RESID, 0), ("proj+lo (EPI_RESID)", C, C, _lib.EPI_RESID, 1),
-                  ("fc1  (EPI_GELU)", 4 * C, C, _lib.EPI_OP16_GELU, 0), ("fc2  (EPI_RESID)", C, 4 * C, _lib.EPI_RESID, 0)]
+                  ("fc1  (EPI_GELU)", 4 * C, C, _lib.EPI_OP16_GELU, 0), ("fc1 shape, no GELU (EPI_OP16)", 4 * C, C, _lib.EPI_OP16, 0),
+                  ("fc1 shape, ReLU (EPI_OP16_RELU)", 4 * C, C, _lib.EPI_OP16_RELU, 0), ("qk shape, plain (EPI_OP16)", 2 * C, C, _lib.EPI_OP16, 0),
+                  ("fc2  (EPI_RESID)", C, 4 * C, _lib.EPI_RESID, 0)]
         # rows: "all" = one GEMM over all B * Tp rows (class + padding rows included), "map" = the B * N patch rows only (token-row map)
         modes = [m for m in a.rows.split(",") if m]
         for name, N, K, epi, lo in shapes:
