@@ -63,9 +63,9 @@ def test_gemm256_rows_beyond_2_31_elements(L):
 
 
 def test_gelu_epilogue_max_abs_error(L):
-    """The fc1 epilogue's GELU is the three-term Abramowitz-Stegun 7.1.25 erfc form (csrc/mhmr_common.h gelu_fast), not erff:
+    """The fc1 epilogue's GELU is max(x, 0) - |x| exp2(P(|x|)) with a fitted degree-5 P (csrc/mhmr_common.h gelu_fast), not erff:
     swept over x = a_m + b_n in [-10, 10] (step ~ 4e-5) through the GEMM itself (A[:, 0] = a, W[:, 0] = 1, bias = b), the stored
-    f16 value stays within 2.6e-5 absolute + half an f16 ulp of the exact x Phi(x)."""
+    f16 value stays within 1.5e-6 absolute + half an f16 ulp of the exact x Phi(x) (rounds 4-5, Abramowitz-Stegun 7.1.25: 2.6e-5)."""
     M, N, K = 4096, 128, 64
     a = torch.linspace(-10, 10, M).half()
     b = torch.linspace(0, 20.0 / M, N)
@@ -80,9 +80,9 @@ def test_gelu_epilogue_max_abs_error(L):
     x = (a.float()[:, None] + b[None, :]).double()
     ref = 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
     err = (out.cpu().double() - ref).abs()
-    bound = 2.6e-5 + 2.0 ** -11 * ref.abs() + 2.0 ** -25         # (+ the f16 subnormal step)
+    bound = 1.5e-6 + 2.0 ** -11 * ref.abs() + 2.0 ** -25         # (+ the f16 subnormal step)
     assert bool((err <= bound).all()), float((err - bound).max())
-    assert float(err.max()) > 1e-6                                # the sweep really exercised the approximation
+    assert float(err.max()) > 1e-6                                # the sweep really reached values whose f16 step shows
 
 
 def swap23(t):

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--img", type=int, default=896)
     ap.add_argument("--tp", type=int, default=0, help="override the padded token count per image (GEMM rows = batch * tp)")
+    ap.add_argument("--tokens", type=int, default=0, help="override the token count T per image (attention only; e.g. 4096: no lone class-token query block, no lone last key)")
     ap.add_argument("--variants", default="0", help="attention kernel forms to time (comma separated, csrc/attention.hip)")
     ap.add_argument("--thr", type=float, default=15.0, help="attention reference-level limit (log2)")
     ap.add_argument("--rows", default="all,map", help="GEMM row modes to time: all (B * Tp rows) and / or map (the B * N patch rows)")
@@ -46,6 +47,9 @@ def main():
     G = a.img // 14
     T = G * G + 1
     Tp = a.tp if a.tp else (T + 63) // 64 * 64
+    if a.tokens:
+        assert a.only == "attn" and a.tokens <= Tp
+        T = a.tokens
     M = B * Tp
     rnd = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(tdt)
     if a.only in ("", "gemm"):

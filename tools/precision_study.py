@@ -32,12 +32,12 @@ ALL = WS + ("xn", "q", "k", "v", "p", "att", "hid", "gelu", "patch")
 
 
 def gelu_fast(x):
+    """csrc/mhmr_common.h gelu_fast (round 6: the tail as exp2 of a degree-5 polynomial)"""
     ax = x.abs()
-    t = 1.0 / (ax * (0.47047 * 0.70710678118654752440) + 1.0)
-    p = t * ((0.7478556 * t - 0.0958798) * t + 0.3480242)
-    u = ax * 0.84932180028801904272
-    q = p * torch.exp2(-(u * u))
-    return torch.clamp(x, min=0) - 0.5 * ax * q
+    p = torch.full_like(ax, -0.0004733092791866511)
+    for c in (0.007084557320922613, -0.051827382296323776, -0.4599924385547638, -1.1507878303527832, -1.000037670135498):
+        p = p * ax + c
+    return torch.clamp(x, min=0) - ax * torch.exp2(p)
 
 
 def ln_folded(t, norm, W, bias, parts, tdt):
