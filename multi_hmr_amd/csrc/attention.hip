@@ -791,6 +791,19 @@ __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const vo
     bool bad = false;
     const bool tail1 = (T & (KB - 1)) == 1 && T > KB;
     const int ntile = tail1 ? T / KB : (T + KB - 1) / KB;
+    // round 6: the lone last key's K row (128 B) and V^T column (64 values, Tp apart: the aligned dword around each) travel to LDS by DMA
+    // NOW, in front of tile 0's copies (wave 0 for the workgroup; landed and visible behind the first tile's wait + barrier), instead of
+    // being fetched from global memory behind the key loop, where every wave then sat out a full memory round trip with nothing else to do
+    char* lone = smem + RING * 2 * KV_TILE_BYTES + 4 * 256;              // [K row: 32 dwords | V^T column: 64 dwords]
+    if (tail1 && w == 0) {
+        const int kl = T - 1;
+        const int klp = (kl & ~12) | ((kl & 4) << 1) | ((kl & 8) >> 1);          // V^T columns are key-permuted (bits 2 <-> 3)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vt + ((size_t)(b * H + h) * 64 + lane) * Tp + (klp & ~1)),
+                                         (__attribute__((address_space(3))) void*)(lone + 128), 4, 0, 0);
+        if (lane < 32)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qk + (row0 + kl) * ldq + C + h * 64 + 2 * lane),
+                                             (__attribute__((address_space(3))) void*)lone, 4, 0, 0);
+    }
     stage(0, 0);
     if constexpr (RING == 3) stage(ntile > 1 ? 1 : 0, 1);
     int buf = 0, nbuf = RING - 1;
@@ -915,7 +928,7 @@ __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const vo
         int kl = T - 1, lane2 = lane;
         asm volatile("" : "+s"(kl), "+v"(lane2));
         const int g2 = lane2 >> 4;
-        const Tt* kp = qk + (row0 + kl) * ldq + C + h * 64 + 8 * g2;
+        const Tt* kp = (const Tt*)lone + 8 * g2;                                  // (the row is in LDS since tile 0)
         float dot[2] = {0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -927,7 +940,11 @@ __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const vo
         }
         const int klp = (kl & ~12) | ((kl & 4) << 1) | ((kl & 8) >> 1);          // V^T columns are key-permuted (bits 2 <-> 3)
         float* vl = (float*)(smem + RING * 2 * KV_TILE_BYTES) + w * 64;
-        vl[lane2] = (float)vt[((size_t)(b * H + h) * 64 + lane2) * Tp + klp];
+        {
+            const uint32_t raw = ((const uint32_t*)(lone + 128))[lane2];          // the aligned dword around V^T[d = lane][klp]
+            const uint16_t bits = (uint16_t)((klp & 1) ? raw >> 16 : raw);
+            vl[lane2] = (float)__builtin_bit_cast(Tt, bits);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        // the strip is written and read by this wave only
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
@@ -979,7 +996,7 @@ int launch_attn16(const void* qk, const void* vt, void* out, int B, int T, int T
                   hipStream_t s, int ldo, int o8) {
     const int nqt = (Tp + 127) / 128;
     const int grid = nqt * H * B;
-    const size_t lds = RING * 2 * KV_TILE_BYTES + 4 * 256;
+    const size_t lds = RING * 2 * KV_TILE_BYTES + 4 * 256 + 384;         // + the lone last key's K row and V^T column
     if (dtype == MHMR_DT_F16)
         hipLaunchKernelGGL((attn16_kernel<MHMR_DT_F16, EARLY, RING>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags, ldo, o8);
     else
