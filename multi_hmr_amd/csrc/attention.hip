@@ -703,6 +703,143 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(const void* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// The lone query of T = 128 n + 1 (every DINOv2 grid whose side is a multiple of 16 patches, + the class token, which is the LAST token
+// row) as a role of its own (round 6, variant 10).  As a 128-query workgroup it was a "ghost": one real query in 128 rows, the whole key
+// loop, a workgroup slot for about as long as a full workgroup -- 512 of 16 896 workgroups at the headline, measured 2.2 % of the launch
+// (tools/kbench.py --tokens 4096 against 4097, profiles/r06_session_n_lone_key_prefetch.txt).  Here a workgroup of four waves takes the
+// class query of one (image, head) on the vector ALU -- exact online softmax in fp32, no reference-level flags -- 32 keys per step, wave w
+// the steps w, w + 4, ...:
+//   scores  lane (key = lane & 31, half = lane >> 5) holds 32 of the key's 64 d (64 B of its K row, four 16-byte loads), 16 v_dot2 against
+//           the query's packed pairs (registers), the halves meet by one lane exchange;
+//   output  lane = d: 64 B of V^T row d (the step's 32 key columns; columns are key-permuted, bits 2 <-> 3), p of column c read from lane
+//           perm(c) by v_readlane -- one FMA per (d, key), the running o[d] is ONE register;
+//   merge   the four waves' (level, sum, o) meet in LDS, wave 0 writes the row.
+// Every global load is an asm statement with counted waits: two register sets per wave, the next step's 8 loads in flight under this
+// step's arithmetic (the first form left the loads to the compiler, which waited for ALL of them before every step -- a full memory round
+// trip per step, 160 us per query: slower than the ghost, profiles/r06_session_o_class_query_role_v1_slower.txt).
+// B H such workgroups in FRONT of the grid (raw block ids: spread over the XCDs), the 128-query workgroups behind.
+// Cost: K and V^T of every head are read once more (0.54 GB per launch at the headline, in the shadow of a compute-bound kernel).
+// (the dot-product BUILTINS, not inline assembly: on gfx90a+ a VALU instruction that reads a dot product's result needs three wait states
+// behind it, and the hazard recogniser cannot see inside an asm statement -- the very first form of this role, with asm, read stale sums)
+template <int DT>
+__device__ __forceinline__ float cls_dot2(uint32_t a, uint32_t b, float acc) {
+    typedef typename Op<DT>::V2 V2;
+    if constexpr (DT == MHMR_DT_F16) return __builtin_amdgcn_fdot2(__builtin_bit_cast(V2, a), __builtin_bit_cast(V2, b), acc, false);
+    else return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(V2, a), __builtin_bit_cast(V2, b), acc, false);
+}
+template <int DT>
+__device__ __forceinline__ float cls_half(uint32_t w, int hi) {      // the low / high 16-bit value of a packed pair as fp32
+    typedef typename Op<DT>::T Tt;
+    return (float)__builtin_bit_cast(Tt, (uint16_t)(hi ? w >> 16 : w));
+}
+// 64 contiguous bytes per lane, requested and NOT waited for (the compiler does not know these registers are in flight: every use must sit
+// behind a cls_wait on the same registers)
+__device__ __forceinline__ void cls_gload64(u32x4& d0, u32x4& d1, u32x4& d2, u32x4& d3, const void* p) {
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
+                 : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void cls_wait(u32x4* a, u32x4* b) {       // at most N of this wave's loads still in flight; a[0..3], b[0..3] are ready
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+}
+template <int DT>
+__device__ __forceinline__ void attn_cls_role(const void* __restrict__ qk_, const void* __restrict__ vt_, void* __restrict__ out_, int T, int Tp,
+                                              int C, int H, int nqt, int* __restrict__ flags, int ldo, int bh, int w, int lane, char* smem) {
+    typedef typename Op<DT>::T Tt;
+    const int b = bh / H, h = bh - b * H;
+    const Tt* qk = (const Tt*)qk_;
+    const Tt* vt = (const Tt*)vt_;
+    const int ldq = 2 * C;
+    const size_t row0 = (size_t)b * Tp;
+    const int key = lane & 31, half = lane >> 5;
+    const Tt* kbase = qk + (row0 + key) * ldq + C + h * 64 + 32 * half;
+    const Tt* vbase = vt + ((size_t)(b * H + h) * 64 + lane) * Tp;
+    const int nst = (T + 31) / 32, last = nst - 1;
+    const int nmine = (nst - w + 3) / 4;                    // this wave's steps: w, w + 4, ... (T >= 129: at least one each)
+    u32x4 q4[4], ka[4], va[4], kb[4], vb[4];
+    auto issue = [&](int st, u32x4* k4, u32x4* v4) {
+        if (st > last) st = last;                           // (past the end: a harmless re-load keeps the load count per step fixed)
+        cls_gload64(k4[0], k4[1], k4[2], k4[3], kbase + (size_t)st * 32 * ldq);
+        cls_gload64(v4[0], v4[1], v4[2], v4[3], vbase + st * 32);
+    };
+    float m_ref = 0.f, l_lane = 0.f, o = 0.f;
+    bool first = true;
+    auto step = [&](int st, const u32x4* k4, const u32x4* v4) {
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sa = cls_dot2<DT>(k4[i][0], q4[i][0], sa);
+            sb = cls_dot2<DT>(k4[i][1], q4[i][1], sb);
+            sa = cls_dot2<DT>(k4[i][2], q4[i][2], sa);
+            sb = cls_dot2<DT>(k4[i][3], q4[i][3], sb);
+        }
+        float sc = sa + sb;
+        sc += __shfl_xor(sc, 32);
+        if (st * 32 + key >= T) sc = -INFINITY;
+        if (first || __any(sc > m_ref + 64.f)) {            // (wave-uniform; after a wave's first step taken only when a key beats the level by 2^64)
+            float mx = sc;
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+            const float f = first ? 0.f : __builtin_amdgcn_exp2f(m_ref - mx);
+            o *= f;
+            l_lane *= f;
+            m_ref = mx;
+            first = false;
+        }
+        const float pv = __builtin_amdgcn_exp2f(sc - m_ref);
+        l_lane += pv;
+        const int pbits = __builtin_bit_cast(int, pv);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const int src = (c & ~12) | ((c & 4) << 1) | ((c & 8) >> 1);           // column c of V^T holds key src of the step
+            const float pc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pbits, src));
+            o = __builtin_fmaf(pc, cls_half<DT>(v4[c >> 3][(c >> 1) & 3], c & 1), o);
+        }
+    };
+    cls_gload64(q4[0], q4[1], q4[2], q4[3], qk + (row0 + T - 1) * ldq + h * 64 + 32 * half);
+    issue(w, ka, va);
+    for (int i = 0; i < nmine; i += 2) {
+        const int st = w + 4 * i;
+        issue(st + 4, kb, vb);
+        cls_wait<8>(ka, va);                                // (the query's four loads are older still)
+        asm volatile("" : "+v"(q4[0]), "+v"(q4[1]), "+v"(q4[2]), "+v"(q4[3]));
+        step(st, ka, va);
+        if (i + 1 < nmine) {
+            issue(st + 8, ka, va);
+            cls_wait<8>(kb, vb);
+            step(st + 4, kb, vb);
+        }
+    }
+    cls_wait<0>(ka, va);                                    // nothing may stay in flight into registers the compiler believes free
+    cls_wait<0>(kb, vb);
+    // ---- the four waves' partial results meet in LDS (the K / V^T ring of the other role: unused here) ----
+    float l = half == 0 ? l_lane : 0.f;                     // (the two halves of a key hold the same p)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) l += __shfl_xor(l, d);
+    float* part = (float*)smem;                             // [4 waves][64 o | level | sum]
+    part[w * 66 + lane] = o;
+    if (lane == 0) { part[w * 66 + 64] = m_ref; part[w * 66 + 65] = l; }
+    __syncthreads();
+    if (w != 0) return;
+    float M = part[64];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) M = fmaxf(M, part[i * 66 + 64]);
+    float O = 0.f, L = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float f = __builtin_amdgcn_exp2f(part[i * 66 + 64] - M);
+        O = __builtin_fmaf(part[i * 66 + lane], f, O);
+        L = __builtin_fmaf(part[i * 66 + 65], f, L);
+    }
+    ((Tt*)out_)[(row0 + T - 1) * (size_t)ldo + h * 64 + lane] = (Tt)(O / L);
+    // the 128-query numbering keeps a workgroup for this query (and for tiles of padding rows behind it); the fallback pass scans their
+    // flags: never flagged
+    if (flags != nullptr)
+        for (int i = 4 * (T / 128) + lane; i < 4 * nqt; i += 64) flags[4 * bh * nqt + i] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // The MODE 3 arithmetic on v_mfma_f32_16x16x32 (round 4, variant 6).  tools/ubench/gemm4w.hip -DMFMA32 showed that the 32x32x16 shape
 // costs 5-8 % more power per flop than 16x16x32 (profiles/r04_mfma_shape_prototype.txt: slower on random data, equal on zeros), and this
 // kernel runs at the lowest clock of the forward (1.6 GHz).  Same workgroup (4 waves x 32 queries, 64-key tiles, 2-slot K / V^T ring,
@@ -721,10 +858,12 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(const void* __restrict__
 //             the previous tile, which every wave has left): ~300 cycles more lead for the landing wait at the top of the next tile;
 //   RING = 3  a third K / V^T slot (48 KiB per workgroup: three workgroups per CU instead of four), copies two tiles ahead behind a COUNTED
 //             wait (the newest tile's four copies per thread may still be in flight).
-template <int DT, bool EARLY = false, int RING = 2>
+// CLSQ (variant 10): launched with ncls > 0 leading workgroups in the class-query role (attn_cls_role above), the 128-query workgroups of the
+//   nfull = T / 128 full query tiles behind them; flags keep the numbering bid = (image, head) * nqt + tile.
+template <int DT, bool EARLY = false, int RING = 2, bool CLSQ = false>
 __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const void* __restrict__ qk_, const void* __restrict__ vt_, void* __restrict__ out_,
                                                         int T, int Tp, int C, int H, int nqt, float limit, int* __restrict__ flags, int ldo,
-                                                        int o8) {
+                                                        int o8, int ncls = 0, int nbh = 0) {
     typedef typename Op<DT>::T Tt;
     typedef typename Op<DT>::V8 V8;
     typedef typename Op<DT>::V4 V4;
@@ -733,7 +872,21 @@ __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const vo
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j15 = lane & 15, g = lane >> 4;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int bid;
+    if constexpr (CLSQ) {
+        if ((int)blockIdx.x < ncls) {
+            if ((int)blockIdx.x >= nbh) return;             // (ncls = the (image, head) count rounded up to a multiple of 8)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            attn_cls_role<DT>(qk_, vt_, out_, T, Tp, C, H, nqt, flags, ldo, (int)blockIdx.x, w, ln, smem);
+            return;
+        }
+        const int nfull = T / QB;
+        const int r = xcd_remap((int)blockIdx.x - ncls, (int)gridDim.x - ncls);
+        bid = (r / nfull) * nqt + r % nfull;
+    } else {
+        bid = xcd_remap(blockIdx.x, gridDim.x);
+    }
     const int qt = bid % nqt, bh = bid / nqt;
     const int b = bh / H, h = bh - b * H;
     if (qt * QB >= T) {
@@ -1005,6 +1158,22 @@ int launch_attn16(const void* qk, const void* vt, void* out, int B, int T, int T
     return 0;
 }
 
+// variant 10: the class query (T = 128 n + 1) on workgroups of its own in front of the grid; any other shape runs variant 6's launch
+int launch_attn16_clsq(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit, int* flags,
+                       hipStream_t s, int ldo, int o8) {
+    if (T % 128 != 1 || T < 129 || o8 != 0) return launch_attn16<false, 2>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8);
+    const int nqt = (Tp + 127) / 128, nbh = B * H;
+    const int ncls = (nbh + 7) / 8 * 8;                                  // one workgroup per (image, head); a multiple of 8: the tile workgroups keep their XCD chunks
+    const int grid = ncls + (T / 128) * nbh;
+    const size_t lds = 2 * 2 * KV_TILE_BYTES + 4 * 256 + 384;
+    if (dtype == MHMR_DT_F16)
+        hipLaunchKernelGGL((attn16_kernel<MHMR_DT_F16, false, 2, true>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags, ldo, o8, ncls, nbh);
+    else
+        hipLaunchKernelGGL((attn16_kernel<MHMR_DT_BF16, false, 2, true>), dim3(grid), dim3(256), lds, s, qk, vt, out, T, Tp, C, H, nqt, limit, flags, ldo, o8, ncls, nbh);
+    MHMR_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int RING>
 int launch_attn64(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit, int* flags,
                   hipStream_t s) {
@@ -1075,9 +1244,9 @@ int mhmr_launch_attention_ex(const void* qk, const void* vt, void* out, int B, i
 // (GemmArgs::lo8 of the output projection).  Only the default form (variant 6 + its fallback) takes a pitch other than C.
 int mhmr_launch_attention_pitch(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype, float limit_log2,
                                 int variant, int* flags, hipStream_t s, int ldo, int o8) {
-    if ((ldo != C || o8 != 0) && (variant < 6 || variant > 9 || ldo < C || o8 < 0 || (o8 > 0 && (o8 < 2 * C || o8 + C > 2 * ldo)))) return MHMR_ERR_BAD_ARG;
+    if ((ldo != C || o8 != 0) && (variant < 6 || variant > 10 || ldo < C || o8 < 0 || (o8 > 0 && (o8 < 2 * C || o8 + C > 2 * ldo)))) return MHMR_ERR_BAD_ARG;
     if (C != H * 64 || Tp % 64 || T > Tp || T <= 0 || limit_log2 < 0.f || limit_log2 > 15.f) return MHMR_ERR_BAD_SHAPE;
-    if ((variant == 0 || (variant >= 6 && variant <= 9)) && flags == nullptr) return MHMR_ERR_BAD_ARG;
+    if ((variant == 0 || (variant >= 6 && variant <= 10)) && flags == nullptr) return MHMR_ERR_BAD_ARG;
     const float limit = exp2f(limit_log2);
     prof_begin(PROF_ATTN, s);
     int rc = 0;
@@ -1107,6 +1276,11 @@ int mhmr_launch_attention_pitch(const void* qk, const void* vt, void* out, int B
                : variant == 7 ? launch_attn16<true, 2>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8)
                : variant == 8 ? launch_attn16<false, 3>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8)
                               : launch_attn16<true, 3>(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8);
+            if (!rc) rc = launch_attn_fallback(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8);
+            break;
+        }
+        case 10: {    // variant 6 with the class query of T = 128 n + 1 on workgroups of its own (attn_cls_role) instead of a 128-query workgroup
+            rc = launch_attn16_clsq(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8);
             if (!rc) rc = launch_attn_fallback(qk, vt, out, B, T, Tp, C, H, dtype, limit, flags, s, ldo, o8);
             break;
         }

@@ -386,7 +386,7 @@ def _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=None, variant=0):
     else:
         flags = torch.full((L.mhmr_attention_flag_count(B, Tp, H),), 7, dtype=torch.int32, device=dev())   # (the call writes every entry)
         _lib.check(L.mhmr_attention16_ex(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), B, T, Tp, C, H, dt, thr, variant,
-                                         flags.data_ptr() if variant in (0, 4, 5, 6, 7, 8, 9) else None, stream()), "attention_ex")
+                                         flags.data_ptr() if variant in (0, 4, 5, 6, 7, 8, 9, 10) else None, stream()), "attention_ex")
         _attn_run.last_flags = flags
     return out.view(B, Tp, C)
 
@@ -400,7 +400,7 @@ def _attn_ref(q, k, v, T, rows=None):
 
 
 @pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
-@pytest.mark.parametrize("variant", [None, 0, 4, 5, 6, 7, 8, 9])     # None = mhmr_attention16; 0 = 32 queries per wave; 4 / 5 = 64 queries per wave; 6 = 16x16x32 MFMAs; 7 / 8 / 9 = its round-6 experiment forms (early copies, three-slot ring, both)
+@pytest.mark.parametrize("variant", [None, 0, 4, 5, 6, 7, 8, 9, 10])     # None = mhmr_attention16; 0 = 32 queries per wave; 4 / 5 = 64 queries per wave; 6 = 16x16x32 MFMAs; 7 / 8 / 9 = its round-6 experiment forms (early copies, three-slot ring, both); 10 = 6 with the class query of T = 128 n + 1 on workgroups of its own
 @pytest.mark.parametrize("B,H,T,pad", [(2, 3, 200, 128), (1, 2, 256, 128), (1, 1, 65, 128), (2, 6, 257, 128), (2, 6, 257, 64), (3, 2, 130, 64),
                                        (1, 2, 577, 64), (2, 1, 40, 64)])
 def test_attention(L, name, dt, tdt, tol, B, H, T, pad, variant):
@@ -413,7 +413,7 @@ def test_attention(L, name, dt, tdt, tol, B, H, T, pad, variant):
 
 
 @pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
-@pytest.mark.parametrize("variant", [0, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 4, 5, 6, 10])
 @pytest.mark.parametrize("target", [10.0, 40.0])
 def test_attention_last_key_rank_one_update(L, name, dt, tdt, tol, target, variant):
     """T = 64 n + 1: the default kernel form folds the lone key of the last tile in as a rank-1 update.  A last key that dominates
@@ -433,7 +433,33 @@ def test_attention_last_key_rank_one_update(L, name, dt, tdt, tol, target, varia
     assert err < (4e-3 if name == "f16" else 3e-2), err
 
 
-@pytest.mark.parametrize("variant", [0, 4, 6])
+@pytest.mark.parametrize("name,dt,tdt,tol", DTYPES)
+@pytest.mark.parametrize("pad", [128, 64, 320])          # 320: a tile of nothing but padding rows behind the class query's
+def test_attention_class_query_role(L, name, dt, tdt, tol, pad):
+    """Variant 10: the lone query of T = 128 n + 1 (the class token) runs on a wave of its own -- exact online softmax on the vector ALU,
+    32 keys per step, a level that moves only when a key beats it by 2^64.  Keys aligned with the class query FORCE that branch (+100 in
+    the exp2 domain at key 200, +30 at key 40: below the threshold, and the class token's own key at +90); every row must match fp64, the
+    class row as closely as the others, and no flag entry may keep the caller's garbage."""
+    B, H, T = 2, 4, 385
+    q, k, v, C, Tp = _attn_inputs(B, H, T, tdt, 21, qscale=3.0, pad=pad)
+    kk = k.float()
+    for (bb, hh, key, target) in [(0, 0, 200, 100.0), (0, 1, 40, 30.0), (1, 3, 384, 90.0), (1, 2, 5, 80.0)]:
+        d = q.float()[bb, T - 1, hh]
+        kk[bb, key, hh] = d / d.norm() ** 2 * target
+    k = kk.to(tdt)
+    got = _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=15.0, variant=10)[:, :T].double()
+    ref = _attn_ref(q, k, v, T)
+    bound = 4e-3 if name == "f16" else 3e-2
+    assert float((got - ref).abs().max()) < bound
+    assert float((got[:, T - 1] - ref[:, T - 1]).abs().max()) < bound / 2          # (fp32 p: no 16-bit rounding of the probabilities)
+    assert torch.isfinite(got).all()
+    assert int((_attn_run.last_flags == 7).sum().item()) == 0                      # every entry written (the fill value was 7)
+    six = _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=15.0, variant=6)[:, :T - 1]
+    ten = _attn_run(L, q, k, v, B, H, T, C, Tp, dt, tdt, thr=15.0, variant=10)[:, :T - 1]
+    assert torch.equal(six, ten)                                                   # the 128-query workgroups are the same code
+
+
+@pytest.mark.parametrize("variant", [0, 4, 6, 10])
 @pytest.mark.parametrize("pad", [128, 64])               # rows per image: 2432 / 4224 / 8576 or 2368 / 4160 / 8512 (vit.padded_tokens)
 @pytest.mark.parametrize("T", [2305, 4097, 8465])        # 672^2, 896^2, 1288^2: 37 / 65 / 133 key tiles, the last one masked
 def test_attention_full_length_against_fp64(L, T, pad, variant):

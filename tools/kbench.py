@@ -84,7 +84,7 @@ def main():
         for rnd_ in range(2):                                                # two interleaved rounds: within-process A/B
             for var in [int(v) for v in a.variants.split(",")]:
                 fn = lambda: _lib.check(L.mhmr_attention16_ex(qk.data_ptr(), vt.data_ptr(), out.data_ptr(), B, T, Tp, C, H, dt, a.thr,
-                                                              var, flags.data_ptr() if var in (0, 4, 5, 6, 7, 8, 9) else None, st), "attn")
+                                                              var, flags.data_ptr() if var in (0, 4, 5, 6, 7, 8, 9, 10) else None, st), "attn")
                 ms = timeit(fn, a.iters)
                 print(f"attention variant {var} B={B} H={H} T={T} {a.dtype}: {ms:8.4f} ms  {4.0 * B * H * T * T * 64 / ms / 1e9:8.1f} TFLOP/s (alg)", flush=True)
     if a.only in ("", "ln"):
