@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define MHMR_VERSION 105   /* 105: mhmr_vit_desc.cls_pstats (row statistics inside the class-row launches); mhmr_vit_desc.v16 (merged qkv launch of a short batch); mhmr_vit_desc.cpad (ViT-S on the 256x256 kernel: C-wide linears as N = 512 with masked columns); mhmr_vit_desc.{splitk, splitk_bytes}, mhmr_splitk_workspace_bytes, mhmr_gemm16_splitk_resid: split-k residual linears for launches that fill less than half the chip (a batch of one); 104: mhmr_vit_desc.{x3, qkv32, hid32}: the f16x3 precision mode (three 16-bit products per term in every backbone linear, fp32 attention); mhmr_gemm16_ex a_k with K = 3 a_k; mhmr_attention_f32; 103: mhmr_attention16_ex variant 6 (the default of mhmr_vit_forward); mhmr_camera_embed(num_bands), mhmr_hph_desc.cam_dim; mhmr_lbs_consts.basis16 layout (high halves for k < Kb - 64); mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
+#define MHMR_VERSION 106   /* 106: mhmr_attention16_ex variant 10 (class query on workgroups of its own; opt-in); the fc1 epilogue's GELU is max(x,0) - |x| exp2(P5(|x|)) (6.4e-7 absolute; was Abramowitz-Stegun 7.1.25, 2.6e-5); 105: mhmr_vit_desc.cls_pstats (row statistics inside the class-row launches); mhmr_vit_desc.v16 (merged qkv launch of a short batch); mhmr_vit_desc.cpad (ViT-S on the 256x256 kernel: C-wide linears as N = 512 with masked columns); mhmr_vit_desc.{splitk, splitk_bytes}, mhmr_splitk_workspace_bytes, mhmr_gemm16_splitk_resid: split-k residual linears for launches that fill less than half the chip (a batch of one); 104: mhmr_vit_desc.{x3, qkv32, hid32}: the f16x3 precision mode (three 16-bit products per term in every backbone linear, fp32 attention); mhmr_gemm16_ex a_k with K = 3 a_k; mhmr_attention_f32; 103: mhmr_attention16_ex variant 6 (the default of mhmr_vit_forward); mhmr_camera_embed(num_bands), mhmr_hph_desc.cam_dim; mhmr_lbs_consts.basis16 layout (high halves for k < Kb - 64); mhmr_person_groups, mhmr_detect_write_cap, mhmr_hph_desc.nvalid (no host round trip for the person set; group / chunk counts of mhmr_hph_forward are upper bounds); 102: mhmr_lbs_consts: extra joints as virtual vertex tiles (Vl, xbary); 101: class token LAST in the token rows, mhmr_vit_block.{v_w2,proj_w2}, mhmr_gemm16_ex, mhmr_cls_linear16, mhmr_attention16_ex variants 4 / 5 */
 
 #define MHMR_OK 0
 #define MHMR_ERR_BAD_ARG (-1)
@@ -234,7 +234,12 @@ int mhmr_attention16(const void* qk, const void* vt, void* out, int B, int T, in
  *   variant 2  level moves when the running maximum leaves a +-8 band (what mhmr_attention16 runs).   flags unused (NULL)
  *   variant 3  variant 2 with 8-wave workgroups.                                        flags unused (NULL)
  *   variant 4 / 5  the arithmetic of variant 0 with 64 queries per wave (two 32-query blocks: a wave's softmax of one block issues in
- *              the shadow of its MFMAs on the other; 256-query workgroups, 3- / 2-slot K/V ring); flags as for variant 0.            */
+ *              the shadow of its MFMAs on the other; 256-query workgroups, 3- / 2-slot K/V ring); flags as for variant 0.
+ *   variant 7 / 8 / 9  round-6 experiment forms of variant 6 (the next tile's copies in front of the score MFMAs, a three-slot K / V^T
+ *              ring, both): same results, none faster inside the forward.
+ *   variant 10 variant 6 with the lone query of T = 128 n + 1 (the class token, the last token row) on workgroups of its own -- vector
+ *              ALU, exact online softmax in fp32 -- instead of a 128-query workgroup with one real row; any other T runs variant 6's
+ *              launch.  Measured slower than variant 6 (round 6): kept for tests and A/B measurements.                                   */
 int mhmr_attention16_ex(const void* qk, const void* vt, void* out, int B, int T, int Tp, int C, int H, int dtype,
                         float limit_log2, int variant, int* flags, void* stream);
 int mhmr_attention_flag_count(int B, int Tp, int H);

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(CSRC, "libmhmr.so")
 SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "attention_f32.hip", "vit_misc.hip", "vit_cls.hip", "hph.hip", "lbs.hip", "preprocess.hip", "evalm.hip", "anny.hip", "capi.hip"]
 HEADERS = ["mhmr_common.h", "mhmr_internal.h", "ln_stats.h", os.path.join("..", "..", "include", "mhmr.h")]
 
-VERSION = 105                       # include/mhmr.h MHMR_VERSION (struct layouts and entry-point semantics)
+VERSION = 106                       # include/mhmr.h MHMR_VERSION (struct layouts and entry-point semantics)
 DT_BF16, DT_F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 EPI_OP16, EPI_OP16_GELU, EPI_OP16_RELU, EPI_RESID, EPI_PATCH, EPI_F32, EPI_VT, EPI_OP16_QK = range(8)
