@@ -59,8 +59,7 @@ template <> struct Op<MHMR_DT_BF16> {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ float pair_sum(uint32_t packed, float acc) {
-        asm("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(packed), "s"(0x3F803F80u));
-        return acc;
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, packed), __builtin_bit_cast(bf16x2, 0x3F803F80u), acc, false);
     }
 };
 template <> struct Op<MHMR_DT_F16> {
@@ -75,13 +74,13 @@ template <> struct Op<MHMR_DT_F16> {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
     // acc + lo + hi of one packed pair (v_dot2_f32_f16 against (1, 1)): two exact products, fp32 accumulation.
-    // HAZARD (gfx90a+): a VALU instruction that is not the same dot opcode needs THREE wait states before it reads a dot product's result,
-    // and the compiler's hazard recogniser does not look inside an asm statement.  Every use of pair_sum is a chain of the same opcode
-    // (accumulator forwarding: no wait) whose sum is next read behind a section of MFMAs; code that consumes a dot product at once must
-    // use __builtin_amdgcn_fdot2 / fdot2_f32_bf16 instead (attention.hip cls_dot2: round 6 found this the hard way).
+    // The BUILTIN, not inline assembly (rounds 3-6 had `asm("v_dot2_f32_f16 ...")` here): on gfx90a+ a VALU instruction that is not the
+    // same dot opcode needs THREE wait states before it reads a dot product's result, and the compiler's hazard recogniser does not look
+    // inside an asm statement.  The shipped attention loop happened to have exactly three instructions in between (the next query block's
+    // dot product, a wait, an MFMA: checked in the ISA); the class-query role of round 6 (attention.hip cls_dot2) did not and read stale
+    // sums.  With the builtin the compiler places the s_nop itself.
     static __device__ __forceinline__ float pair_sum(uint32_t packed, float acc) {
-        asm("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(packed), "s"(0x3C003C00u));
-        return acc;
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, packed), __builtin_bit_cast(f16x2, 0x3C003C00u), acc, false);
     }
 };
 
