@@ -860,50 +860,24 @@ __device__ __forceinline__ void attn_cls_role(const void* __restrict__ qk_, cons
 //             wait (the newest tile's four copies per thread may still be in flight).
 // CLSQ (variant 10): launched with ncls > 0 leading workgroups in the class-query role (attn_cls_role above), the 128-query workgroups of the
 //   nfull = T / 128 full query tiles behind them; flags keep the numbering bid = (image, head) * nqt + tile.
-template <int DT, bool EARLY = false, int RING = 2, bool CLSQ = false>
-__global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const void* __restrict__ qk_, const void* __restrict__ vt_, void* __restrict__ out_,
-                                                        int T, int Tp, int C, int H, int nqt, float limit, int* __restrict__ flags, int ldo,
-                                                        int o8, int ncls = 0, int nbh = 0) {
+// The body of attn16_kernel behind its early exits, for NQB = 2 (a wave's two 16-query blocks) or NQB = 1 (round 6, session R: the LAST workgroup
+// of an image whose real queries all sit in wave 0's first block -- T = 128 n + 1 ... 128 n + 16; at T = 128 n + 1, every DINOv2 grid with a side
+// of a multiple of 16 patches, that workgroup holds ONE real query and was measured at 2.2 % of the launch: half the per-tile work of its only
+// active wave was rows of padding).  Rows 16 ... 31 of that workgroup's first wave are then never stored (they keep what was allocated: zero).
+// The split became possible (no spill beside the 128-register key loop) with the copies' addresses as a scalar base + a 32-bit lane offset.
+template <int DT, bool EARLY, int RING, int NQB>
+__device__ __forceinline__ void attn16_tail(const typename Op<DT>::T* __restrict__ qk, const typename Op<DT>::T* __restrict__ vt, void* __restrict__ out_,
+                                            int T, int Tp, int C, int H, float limit, int* __restrict__ flags, int ldo, int o8, int bid, int qt, int b, int h,
+                                            int w, int lane, int j15, int g, int tid, char* smem, size_t row0, int ldq, bool active, bool in_buf) {
     typedef typename Op<DT>::T Tt;
     typedef typename Op<DT>::V8 V8;
     typedef typename Op<DT>::V4 V4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | Vt tile] + one 64-float strip per wave
     constexpr int QB = 128;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j15 = lane & 15, g = lane >> 4;
-    int bid;
-    if constexpr (CLSQ) {
-        if ((int)blockIdx.x < ncls) {
-            if ((int)blockIdx.x >= nbh) return;             // (ncls = the (image, head) count rounded up to a multiple of 8)
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            attn_cls_role<DT>(qk_, vt_, out_, T, Tp, C, H, nqt, flags, ldo, (int)blockIdx.x, w, ln, smem);
-            return;
-        }
-        const int nfull = T / QB;
-        const int r = xcd_remap((int)blockIdx.x - ncls, (int)gridDim.x - ncls);
-        bid = (r / nfull) * nqt + r % nfull;
-    } else {
-        bid = xcd_remap(blockIdx.x, gridDim.x);
-    }
-    const int qt = bid % nqt, bh = bid / nqt;
-    const int b = bh / H, h = bh - b * H;
-    if (qt * QB >= T) {
-        if (lane == 0) flags[4 * bid + w] = 0;
-        return;
-    }
-    const Tt* qk = (const Tt*)qk_;
-    const Tt* vt = (const Tt*)vt_;
-    const int ldq = 2 * C;
-    const size_t row0 = (size_t)b * Tp;
-    const bool active = qt * QB + 32 * w < T;
-    const bool in_buf = qt * QB + 32 * w < Tp;
     // Q fragments (second operand): lane (j, g) holds Q[16 qb + j][32 ks + 8 g + 0..7]
     V8 qf[2][2] = {};
     if (in_buf) {
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
+        for (int qb = 0; qb < NQB; ++qb) {
             const Tt* qp = qk + (row0 + qt * QB + 32 * w + 16 * qb + j15) * ldq + h * 64 + 8 * g;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) qf[qb][ks] = *(const V8*)(qp + 32 * ks);
@@ -913,17 +887,28 @@ __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const vo
     const int srow = tid >> 3;
     const int kchunk = (tid & 7) ^ (((srow >> 1) & 3) | (((srow >> 4) & 1) << 2));
     const int vchunk = (tid & 7) ^ ((srow >> 1) & 7);
-    const Tt* k_src = qk + (row0 + srow) * ldq + C + h * 64 + kchunk * 8;
-    const Tt* v_src = vt + ((size_t)(b * H + h) * 64 + srow) * Tp + vchunk * 8;
+    // (addresses as a wave-uniform 64-bit base, advanced on the scalar unit, + a 32-bit lane offset that never changes: the copies take the
+    // SGPR-base form of global_load_lds -- no 64-bit vector add per copy, two registers less than two 64-bit lane pointers)
+    const uint32_t k_lane = (uint32_t)(srow * ldq + kchunk * 8) * 2u;
+    const uint32_t v_lane = (uint32_t)(srow * Tp + vchunk * 8) * 2u;
+    const char* k_base = (const char*)(qk + row0 * ldq + C + h * 64);
+    const char* v_base = (const char*)(vt + (size_t)(b * H + h) * 64 * Tp);
     auto stage = [&](int jt, int buf) {
         char* sk = smem + buf * (2 * KV_TILE_BYTES) + w * 1024;
         char* sv = sk + KV_TILE_BYTES;
-        const Tt* kp = k_src + (size_t)jt * KB * ldq;
-        const Tt* vp = v_src + jt * KB;
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) glds16(kp + (size_t)(32 * ps) * ldq, sk + ps * 4096);
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) glds16(vp + (size_t)(32 * ps) * Tp, sv + ps * 4096);
+        const char* kp = k_base + (size_t)jt * KB * ldq * 2;
+        const char* vp = v_base + (size_t)jt * KB * 2;
+        // (the 32-bit lane offsets pass through an empty asm HERE: instruction selection works per basic block, and a zero-extension
+        // hoisted out of the key loop would leave it a 64-bit vector add per copy again)
+        uint32_t kl = k_lane, vl_ = v_lane;
+        asm volatile("" : "+v"(kl), "+v"(vl_));
+        const char* kp1 = kp + (size_t)32 * ldq * 2;
+        const char* vp1 = vp + (size_t)32 * Tp * 2;
+        asm volatile("" : "+s"(kp1), "+s"(vp1));          // (scalar registers: base + row offset is added on the scalar unit, not per lane)
+        glds16(kp + kl, sk);
+        glds16(kp1 + kl, sk + 4096);
+        glds16(vp + vl_, sv);
+        glds16(vp1 + vl_, sv + 4096);
     };
     // fragment addresses inside a tile.  K: row = 32 m + 8 xy + i + (i & 8), chunk 4 ks + g; V^T: row = 16 db + i, chunk 4 m + g.  Both
     // swizzle terms depend on the lane only ((32 m + 8 xy) and 16 db leave the bits they use alone), and chunk 4 + c is chunk c with bit 2
@@ -939,7 +924,7 @@ __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const vo
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) o[db][qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int qb = 0; qb < NQB; ++qb) o[db][qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_ref[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
     bool bad = false;
     const bool tail1 = (T & (KB - 1)) == 1 && T > KB;
@@ -987,7 +972,7 @@ __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const vo
 #pragma unroll
             for (int xy = 0; xy < 2; ++xy)
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) sc[m][xy][qb] = (f32x4){-m_ref[qb], -m_ref[qb], -m_ref[qb], -m_ref[qb]};
+                for (int qb = 0; qb < NQB; ++qb) sc[m][xy][qb] = (f32x4){-m_ref[qb], -m_ref[qb], -m_ref[qb], -m_ref[qb]};
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -999,7 +984,7 @@ __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const vo
 #pragma unroll
                 for (int xy = 0; xy < 2; ++xy)
 #pragma unroll
-                    for (int qb = 0; qb < 2; ++qb) sc[m][xy][qb] = Op<DT>::mfma16(kf[xy], qf[qb][ks], sc[m][xy][qb]);
+                    for (int qb = 0; qb < NQB; ++qb) sc[m][xy][qb] = Op<DT>::mfma16(kf[xy], qf[qb][ks], sc[m][xy][qb]);
             }
         __builtin_amdgcn_s_setprio(0);
         if constexpr (!EARLY) stage(jnext, nbuf_now);
@@ -1017,7 +1002,7 @@ __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const vo
         // ---- reference level: the exact row maximum of tile 0 (over the four lanes of a query), then fixed ----
         if (jt == 0) {
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
+            for (int qb = 0; qb < NQB; ++qb) {
                 float mt = sc[0][0][qb][0];
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
@@ -1042,7 +1027,7 @@ __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const vo
 #pragma unroll
             for (int xy = 0; xy < 2; ++xy)
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb)
+                for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sc[m][xy][qb][r] = __builtin_amdgcn_exp2f(sc[m][xy][qb][r]);
         // ---- O^T += V^T . P^T ; row sums from the rounded values (v_dot2 of each packed pair against (1, 1)) ----
@@ -1052,7 +1037,7 @@ __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const vo
         for (int m = 0; m < 2; ++m) {
             V8 pf[2];
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
+            for (int qb = 0; qb < NQB; ++qb) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { pf[qb][e] = (Tt)sc[m][0][qb][e]; pf[qb][4 + e] = (Tt)sc[m][1][qb][e]; }
                 const u32x4 pw = __builtin_bit_cast(u32x4, pf[qb]);
@@ -1065,11 +1050,11 @@ __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const vo
             for (int db = 0; db < 4; ++db) {
                 const V8 vf = *(const V8*)(sv + vofs[m] + db * 2048);
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) o[db][qb] = Op<DT>::mfma16(vf, pf[qb], o[db][qb]);
+                for (int qb = 0; qb < NQB; ++qb) o[db][qb] = Op<DT>::mfma16(vf, pf[qb], o[db][qb]);
             }
         }
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
+        for (int qb = 0; qb < NQB; ++qb) {
             l_run[qb] += psum[qb];
             bad |= !(psum[qb] <= limit);          // all p > 0: a lane sum <= limit proves every p of the lane finite in 16 bits
         }
@@ -1087,7 +1072,7 @@ __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const vo
         for (int ks = 0; ks < 2; ++ks) {
             const V8 kf = *(const V8*)(kp + 32 * ks);
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
+            for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dot[qb] = __builtin_fmaf((float)qf[qb][ks][e], (float)kf[e], dot[qb]);
         }
@@ -1100,7 +1085,7 @@ __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const vo
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        // the strip is written and read by this wave only
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
+        for (int qb = 0; qb < NQB; ++qb) {
             float d = dot[qb];
             d += __shfl_xor(d, 16);
             d += __shfl_xor(d, 32);
@@ -1125,7 +1110,7 @@ __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const vo
     int lane3 = lane;
     asm volatile("" : "+v"(lane3));
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < NQB; ++qb) {
         float l_tot = l_run[qb];
         l_tot += __shfl_xor(l_tot, 16);
         l_tot += __shfl_xor(l_tot, 32);
@@ -1142,6 +1127,49 @@ __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const vo
             if (o8 > 0) *(uint32_t*)(op8 + 16 * db) = pack_bf8x4(f[0], f[1], f[2], f[3]);      // the output projection's fp8 low-half range
         }
     }
+}
+
+template <int DT, bool EARLY = false, int RING = 2, bool CLSQ = false>
+__global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void attn16_kernel(const void* __restrict__ qk_, const void* __restrict__ vt_, void* __restrict__ out_,
+                                                        int T, int Tp, int C, int H, int nqt, float limit, int* __restrict__ flags, int ldo,
+                                                        int o8, int ncls = 0, int nbh = 0) {
+    typedef typename Op<DT>::T Tt;
+    typedef typename Op<DT>::V8 V8;
+    typedef typename Op<DT>::V4 V4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | Vt tile] + one 64-float strip per wave
+    constexpr int QB = 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j15 = lane & 15, g = lane >> 4;
+    int bid;
+    if constexpr (CLSQ) {
+        if ((int)blockIdx.x < ncls) {
+            if ((int)blockIdx.x >= nbh) return;             // (ncls = the (image, head) count rounded up to a multiple of 8)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            attn_cls_role<DT>(qk_, vt_, out_, T, Tp, C, H, nqt, flags, ldo, (int)blockIdx.x, w, ln, smem);
+            return;
+        }
+        const int nfull = T / QB;
+        const int r = xcd_remap((int)blockIdx.x - ncls, (int)gridDim.x - ncls);
+        bid = (r / nfull) * nqt + r % nfull;
+    } else {
+        bid = xcd_remap(blockIdx.x, gridDim.x);
+    }
+    const int qt = bid % nqt, bh = bid / nqt;
+    const int b = bh / H, h = bh - b * H;
+    if (qt * QB >= T) {
+        if (lane == 0) flags[4 * bid + w] = 0;
+        return;
+    }
+    const Tt* qk = (const Tt*)qk_;
+    const Tt* vt = (const Tt*)vt_;
+    const int ldq = 2 * C;
+    const size_t row0 = (size_t)b * Tp;
+    const bool active = qt * QB + 32 * w < T;
+    const bool in_buf = qt * QB + 32 * w < Tp;
+    if (T - qt * QB <= 16) attn16_tail<DT, EARLY, RING, 1>(qk, vt, out_, T, Tp, C, H, limit, flags, ldo, o8, bid, qt, b, h, w, lane, j15, g, tid, smem, row0, ldq, active, in_buf);
+    else attn16_tail<DT, EARLY, RING, 2>(qk, vt, out_, T, Tp, C, H, limit, flags, ldo, o8, bid, qt, b, h, w, lane, j15, g, tid, smem, row0, ldq, active, in_buf);
 }
 
 template <bool EARLY = false, int RING = 2>

@@ -43,20 +43,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const int srow = tid >> 3;                                   // 0..31 (+32 per pass)
     const int schunk = (tid & 7) ^ ((tid >> 4) & 7);             // logical chunk landing at phys chunk tid&7
     const int m0p = (int)mhmr_phys_row(m0, g.img_rows, g.img_stride);      // physical first activation / output row (mhmr_internal.h)
-    const T* a_src = (const T*)g.A + (size_t)(m0p + srow) * g.lda + schunk * 8;
-    const T* w_src = (const T*)g.W + (size_t)(n0 + srow) * g.ldw + schunk * 8;
-    const size_t a_pass = (size_t)32 * g.lda, w_pass = (size_t)32 * g.ldw;
+    // (round 6: a wave-uniform 64-bit tile base, advanced on the scalar unit, + a 32-bit BYTE offset per lane that never changes: the copies take
+    // the SGPR-base form of global_load_lds -- rounds 1-5 kept two 64-bit lane pointers and paid a 64-bit vector add per copy, eight per k tile)
+    const char* a_base = (const char*)((const T*)g.A + (size_t)m0p * g.lda);
+    const char* w_base = (const char*)((const T*)g.W + (size_t)n0 * g.ldw);
+    const uint32_t a_lane = ((uint32_t)srow * (uint32_t)g.lda + (uint32_t)(schunk * 8)) * (uint32_t)sizeof(T);
+    const uint32_t w_lane = ((uint32_t)srow * (uint32_t)g.ldw + (uint32_t)(schunk * 8)) * (uint32_t)sizeof(T);
+    const size_t a_pass = (size_t)32 * g.lda * sizeof(T), w_pass = (size_t)32 * g.ldw * sizeof(T);
 
     const int nta = g.a_k > 0 ? g.a_k / BK : g.K / BK;
     auto stage = [&](int kt, int buf) {
         char* sa = smem + buf * (2 * TILE_BYTES) + w * 1024;
         char* sw = sa + TILE_BYTES;
-        const T* ap = a_src + (kt >= nta ? kt - nta : kt) * BK;            // low-half weight pass: the activation's k tiles wrap around
-        const T* wp = w_src + kt * BK;
+        const char* ap = a_base + (size_t)((kt >= nta ? kt - nta : kt) * BK) * sizeof(T);      // low-half weight pass: the activation's k tiles wrap around
+        const char* wp = w_base + (size_t)(kt * BK) * sizeof(T);
+        // (the lane offsets pass through an empty asm HERE: instruction selection works per basic block, a zero-extension hoisted out of the
+        // k loop would leave a 64-bit vector add per copy; the row-pass bases are pinned to scalar registers for the same reason)
+        uint32_t al = a_lane, wl = w_lane;
+        asm volatile("" : "+v"(al), "+v"(wl));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            glds16(ap + i * a_pass, sa + i * 4096);
-            glds16(wp + i * w_pass, sw + i * 4096);
+            const char* api = ap + i * a_pass;
+            const char* wpi = wp + i * w_pass;
+            asm volatile("" : "+s"(api), "+s"(wpi));
+            glds16(api + al, sa + i * 4096);
+            glds16(wpi + wl, sw + i * 4096);
         }
     };
 

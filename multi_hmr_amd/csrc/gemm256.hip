@@ -207,10 +207,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
             const int t2 = w * 64 + fresh_lane();
             lane_off = (uint32_t)(t2 >> 3) * (uint32_t)ld + (uint32_t)((((t2 & 7) ^ ((t2 >> 4) & 7))) * 8);
         }
-        const uint32_t o = lane_off + (uint32_t)(128 * half) * (uint32_t)ld + (uint32_t)(kt * 64);
+        // (BYTE offsets in 32 bits: the copies then take the SGPR-base form of global_load_lds -- scalar base + zero-extended lane offset --
+        // instead of a 64-bit vector shift-and-add per copy: element offsets are shifted AFTER the extension, which that form cannot express)
+        const uint32_t o = (lane_off + (uint32_t)(128 * half) * (uint32_t)ld + (uint32_t)(kt * 64)) * (uint32_t)sizeof(T);
         char* d = smem + lds_off + w * 1024;
-        glds16(base + o, d);
-        glds16(base + (o + 64u * (uint32_t)ld), d + 8192);
+        glds16((const char*)base + o, d);
+        glds16((const char*)base + (o + 64u * (uint32_t)sizeof(T) * (uint32_t)ld), d + 8192);
     };
 
     // ---- fragment read addressing (16-row sub-tiles; chunk = 4*ks + g4 within the 128-byte row) ----

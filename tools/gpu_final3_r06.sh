@@ -1,5 +1,5 @@
 #!/bin/bash
-# FOURTH final validation (pair_sum as a builtin: one library change) -- THIRD final validation of round 6 (after sessions M-P: the GELU as exp2 of a polynomial, the lone key by DMA, the class-query role: library changes, so the whole evidence set again;
+# FIFTH final validation (sessions R-T: copies with an SGPR base in all three MFMA kernels, the half-work ghost) -- FOURTH (pair_sum as a builtin) -- THIRD final validation of round 6 (after sessions M-P: the GELU as exp2 of a polynomial, the lone key by DMA, the class-query role: library changes, so the whole evidence set again;
 # the SMPL-X A/B, the pose timeline and config 2's trace of the first final run stand: those kernels did not change).
 # Final validation of round 6 on the GPU box, all on ONE build (the library says which sources it was made from): the whole -m gpu suite,
 # smoke(), the default bench command, the bench under an RCCL group of one, the forward's bit-reproducibility, the SMPL-X layer A/B + the
