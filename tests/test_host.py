@@ -155,6 +155,18 @@ def test_gelu_exp2_polynomial_error_bound():
         assert repr(abs(c)) + "f" in body, c
 
 
+def test_no_dot_product_hides_inside_inline_assembly():
+    """gfx90a+: a VALU instruction that is not the same dot opcode needs three wait states before it reads a dot product's result, and
+    hipcc's hazard recogniser does not look inside asm statements (round 6: a kernel with `asm("v_dot2_f32_f16 ...")` read stale sums;
+    DESIGN 12.8).  Dot products go through __builtin_amdgcn_fdot2 / fdot2_f32_bf16; no csrc file may bring the asm form back."""
+    csrc = os.path.join(ROOT, "multi_hmr_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            text = re.sub(r"//[^\n]*", "", open(os.path.join(csrc, f)).read())          # (comments may quote the old form)
+            for m in re.finditer(r'asm\s*(volatile)?\s*\(\s*"([^"]*)"', text):
+                assert "v_dot" not in m.group(2), (f, m.group(2))
+
+
 def test_pack_smplx_rejects_a_basis_outside_the_f16_pair_range(smplx_data):
     """The blend basis travels as an f16 pair scaled by 2^10: a body model whose blend shapes are 100x larger would overflow
     silently on the GPU; pack_smplx refuses it."""
